@@ -1,0 +1,293 @@
+"""
+Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; the reference never
+travels to the GPU box).  The committed ``*.npz`` files hold data only: inputs
+(seeded recipes spelled out below), the reference's parameters, and the
+reference's outputs.  Usage:  python tests/golden/make_golden.py
+
+Cases:
+  g1_bs_eval_B{7,64,200}  eval forward, demo.py config, until_T path
+  g2_bs_grads_B64         dropout 0, train(): loss, 18 grads, Adam x1 / x5
+  g3_ckpt_{BS,Heston,OU}  shipped checkpoints, N=200 seed-0 data, 3 known answers
+  g4_data_{BS,OU,Heston}  N=50 seed-0 datasets (bit-exact f64) + cond. exp.
+  g5_masked               PhysioNet-shaped masked batch, loss/path/grads
+  g6_*                    variants: input_current_t, easy loss, no residual,
+                          func_appl_X, use_rnn, sparse times (B=5), empty slice
+"""
+import contextlib
+import copy
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference')
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import NJODE.models as ref_models
+    import NJODE.data_utils as ref_data
+    import NJODE.stock_model as ref_stock
+
+from njode_amd import synthetic_physionet  # noqa: E402
+
+NN = ((50, 'tanh'), (50, 'tanh'))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def ref_dataset(name, n_paths, seed=0):
+    """reference create_dataset protocol without the file bookkeeping
+    (data_utils.py:73-81)."""
+    hp = copy.deepcopy(ref_data.hyperparam_default)
+    hp['nb_paths'] = n_paths
+    hp['model_name'] = name
+    np.random.seed(seed)
+    sm = ref_stock.STOCK_MODELS[name](**hp)
+    paths, dt = sm.generate_paths()
+    obs = (np.random.random(size=(paths.shape[0], paths.shape[2])) <
+           hp['obs_perc']) * 1
+    nb_obs = np.sum(obs[:, 1:], axis=1)
+    hp['dt'] = dt
+    return paths, obs, nb_obs, hp, sm
+
+
+def ref_collate(paths, obs, nb_obs, dt, idx, func_names=None):
+    items = [{'idx': [i], 'stock_path': paths[[i]], 'observed_dates': obs[[i]],
+              'nb_obs': nb_obs[[i]], 'dt': dt} for i in idx]
+    if func_names is None:
+        return ref_data.custom_collate_fn(items)
+    fn, _ = ref_data.CustomCollateFnGen(func_names)
+    return fn(items)
+
+
+def build(cfg, seed=0):
+    torch.manual_seed(seed)
+    return quiet(ref_models.NJODE, **cfg)
+
+
+def sd_arrays(model):
+    return {'sd/' + k: v.detach().numpy().copy()
+            for k, v in model.state_dict().items()}
+
+
+def batch_arrays(b, with_M=False):
+    out = {'times': np.asarray(b['times'], dtype=np.float64),
+           'time_ptr': np.asarray(b['time_ptr'], dtype=np.int64),
+           'X': b['X'].numpy(), 'obs_idx': b['obs_idx'].numpy(),
+           'start_X': b['start_X'].numpy(),
+           'n_obs_ot': np.asarray(b['n_obs_ot'])}
+    if with_M:
+        out['M'] = b['M'].numpy()
+    return out
+
+
+def save(name, cfg, arrays):
+    arrays = dict(arrays)
+    arrays['cfg_json'] = np.array(json.dumps(cfg))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('{:28s} {:8.1f} KB'.format(name, os.path.getsize(path) / 1024))
+
+
+def demo_cfg(d=1, H=10, dropout=0.1, **options):
+    return dict(input_size=d, hidden_size=H, output_size=d, ode_nn=NN,
+                readout_nn=NN, enc_nn=NN, use_rnn=False, bias=True,
+                dropout_rate=dropout, options=options)
+
+
+def eval_outputs(model, b, delta_t, T, M=None, until_T=True):
+    model.eval()
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = model(
+            b['times'], b['time_ptr'], b['X'], b['obs_idx'], delta_t, T,
+            b['start_X'], b['n_obs_ot'], return_path=True, get_loss=True,
+            until_T=until_T, M=M)
+    return {'hT': hT.numpy(), 'loss': np.float64(loss.item()),
+            'path_t': np.asarray(path_t, dtype=np.float64),
+            'path_h': path_h.numpy(), 'path_y': path_y.numpy()}
+
+
+def grad_outputs(model, b, delta_t, T, M=None):
+    model.train()
+    model.zero_grad()
+    hT, loss = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], delta_t,
+                     T, b['start_X'], b['n_obs_ot'], return_path=False,
+                     get_loss=True, M=M)
+    loss.backward()
+    out = {'train_loss': np.float64(loss.item()), 'train_hT': hT.detach().numpy()}
+    for k, p in model.named_parameters():
+        out['grad/' + k] = p.grad.numpy().copy()
+    return out
+
+
+def g1():
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    for B in (7, 64, 200):
+        cfg = demo_cfg()
+        model = build(cfg)
+        b = ref_collate(paths, obs, nb_obs, hp['dt'], range(B))
+        arrays = {**sd_arrays(model), **batch_arrays(b),
+                  'delta_t': hp['dt'], 'T': hp['maturity']}
+        out = eval_outputs(model, b, hp['dt'], hp['maturity'])
+        if B == 200:
+            out.pop('path_h')
+        arrays.update(out)
+        # training-style call: no until_T, no path
+        model.eval()
+        with torch.no_grad():
+            hT2, loss2 = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'],
+                               hp['dt'], hp['maturity'], b['start_X'],
+                               b['n_obs_ot'])
+        arrays['hT_lastobs'] = hT2.numpy()
+        arrays['loss_lastobs'] = np.float64(loss2.item())
+        save('g1_bs_eval_B{}'.format(B), cfg, arrays)
+
+
+def g2():
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    cfg = demo_cfg(dropout=0.0)
+    model = build(cfg)
+    b = ref_collate(paths, obs, nb_obs, hp['dt'], range(64))
+    arrays = {**sd_arrays(model), **batch_arrays(b),
+              'delta_t': hp['dt'], 'T': hp['maturity']}
+    arrays.update(grad_outputs(model, b, hp['dt'], hp['maturity']))
+    # Adam(lr=1e-3, weight_decay=5e-4) x1 and x5 on the same batch
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0005)
+    model.train()
+    losses = []
+    for step in range(1, 6):
+        opt.zero_grad()
+        _, loss = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'],
+                        hp['dt'], hp['maturity'], b['start_X'], b['n_obs_ot'])
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        if step in (1, 5):
+            for k, v in model.state_dict().items():
+                arrays['adam{}/{}'.format(step, k)] = v.numpy().copy()
+    arrays['adam_losses'] = np.asarray(losses, dtype=np.float64)
+    save('g2_bs_grads_B64', cfg, arrays)
+
+
+def g3():
+    for mid, name, tag in ((1, 'BlackScholes', 'BS'), (2, 'Heston', 'Heston'),
+                           (3, 'OrnsteinUhlenbeck', 'OU')):
+        ck = torch.load('/root/reference/data/saved_models/id-{}/'
+                        'last_checkpoint/checkpt.tar'.format(mid),
+                        weights_only=False)
+        cfg = demo_cfg(which_loss='standard', residual_enc_dec=True)
+        model = build(cfg)
+        model.load_state_dict(ck['model_state_dict'])
+        model.weight = ck['weight']
+        paths, obs, nb_obs, hp, sm = ref_dataset(name, 200)
+        b = ref_collate(paths, obs, nb_obs, hp['dt'], range(200))
+        dt, T = hp['dt'], hp['maturity']
+        model.eval()
+        with torch.no_grad():
+            _, loss = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt,
+                            T, b['start_X'], b['n_obs_ot'])
+            msd = model.evaluate(b['times'], b['time_ptr'], b['X'],
+                                 b['obs_idx'], dt, T, b['start_X'],
+                                 b['n_obs_ot'], sm)
+        opt = sm.get_optimal_loss(b['times'], b['time_ptr'], b['X'].numpy(),
+                                  b['obs_idx'].numpy(), dt, T,
+                                  b['start_X'].numpy(), b['n_obs_ot'].numpy(),
+                                  weight=model.weight)
+        arrays = {**sd_arrays(model), 'dataset': np.array(name),
+                  'ckpt_epoch': ck['epoch'], 'ckpt_weight': ck['weight'],
+                  'eval_loss': np.float64(loss.item()),
+                  'optimal_loss': np.float64(opt), 'msd_cond_exp': np.float64(msd)}
+        print('   ', tag, loss.item(), opt, msd)
+        save('g3_ckpt_{}'.format(tag), cfg, arrays)
+
+
+def g4():
+    for name, tag in (('BlackScholes', 'BS'), ('OrnsteinUhlenbeck', 'OU'),
+                      ('Heston', 'Heston')):
+        paths, obs, nb_obs, hp, sm = ref_dataset(name, 50)
+        b = ref_collate(paths, obs, nb_obs, hp['dt'], range(50))
+        loss, ct, cy = sm.compute_cond_exp(
+            b['times'], b['time_ptr'], b['X'].numpy(), b['obs_idx'].numpy(),
+            hp['dt'], hp['maturity'], b['start_X'].numpy(),
+            b['n_obs_ot'].numpy(), return_path=True, get_loss=True)
+        arrays = {'paths': paths, 'observed_dates': obs, 'nb_obs': nb_obs,
+                  **batch_arrays(b), 'delta_t': hp['dt'], 'T': hp['maturity'],
+                  'cond_loss': np.float64(loss), 'cond_t': ct, 'cond_y': cy}
+        hp_json = {k: v for k, v in hp.items()}
+        save('g4_data_{}'.format(tag), hp_json, arrays)
+
+
+def g5():
+    b = synthetic_physionet.make_batch(batch_size=8, n_grid=150,
+                                       n_obs_range=(5, 20), seed=0)
+    cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN,
+               readout_nn=NN, enc_nn=NN, use_rnn=False, bias=True,
+               dropout_rate=0.0, options={'masked': True})
+    model = build(cfg)
+    arrays = {**sd_arrays(model), **batch_arrays(b, with_M=True),
+              'delta_t': b['delta_t'], 'T': b['T']}
+    arrays.update(eval_outputs(model, b, b['delta_t'], b['T'], M=b['M']))
+    arrays.update(grad_outputs(model, b, b['delta_t'], b['T'], M=b['M']))
+    save('g5_masked', cfg, arrays)
+
+
+def g6():
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    dt, T = hp['dt'], hp['maturity']
+    variants = {
+        'g6_current_t': (demo_cfg(dropout=0.0, input_current_t=True), 16, None),
+        'g6_easy_loss': (demo_cfg(dropout=0.0, which_loss='easy'), 16, None),
+        'g6_no_residual': (demo_cfg(dropout=0.0, residual_enc_dec=False), 16,
+                           None),
+        'g6_power2': (demo_cfg(d=2, dropout=0.0), 16, ['power-2']),
+        'g6_sparse_B5': (demo_cfg(dropout=0.0), 5, None),
+        'g6_weight075': (dict(demo_cfg(dropout=0.0), weight=0.75), 16, None),
+        'g6_relu_w20': (dict(demo_cfg(dropout=0.0),
+                             ode_nn=((20, 'relu'), (20, 'relu')),
+                             enc_nn=((20, 'relu'), (20, 'relu')),
+                             readout_nn=((20, 'relu'), (20, 'relu'))), 16, None),
+        'g6_linear_nets': (dict(demo_cfg(dropout=0.0), ode_nn=None, enc_nn=None,
+                                readout_nn=None), 16, None),
+    }
+    for name, (cfg, B, funcs) in variants.items():
+        model = build(cfg)
+        b = ref_collate(paths, obs, nb_obs, dt, range(B), funcs)
+        arrays = {**sd_arrays(model), **batch_arrays(b), 'delta_t': dt, 'T': T}
+        arrays.update(eval_outputs(model, b, dt, T))
+        arrays.update(grad_outputs(model, b, dt, T))
+        save(name, cfg, arrays)
+
+    # GRU jump
+    cfg = dict(demo_cfg(dropout=0.0), use_rnn=True)
+    model = build(cfg)
+    b = ref_collate(paths, obs, nb_obs, dt, range(16))
+    arrays = {**sd_arrays(model), **batch_arrays(b), 'delta_t': dt, 'T': T}
+    arrays.update(eval_outputs(model, b, dt, T))
+    arrays.update(grad_outputs(model, b, dt, T))
+    save('g6_use_rnn', cfg, arrays)
+
+    # off-grid delta_t: Euler step 0.004 against observations on the 0.01 grid
+    # => 2 full steps + 1 partial step per grid interval, and an until_T tail
+    cfg = demo_cfg(dropout=0.0)
+    model = build(cfg)
+    b = ref_collate(paths, obs, nb_obs, dt, range(6))
+    arrays = {**sd_arrays(model), **batch_arrays(b), 'delta_t': 0.004, 'T': 1.05}
+    arrays.update(eval_outputs(model, b, 0.004, 1.05))
+    arrays.update(grad_outputs(model, b, 0.004, 1.05))
+    save('g6_offgrid_dt', cfg, arrays)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    for fn in (g1, g2, g3, g4, g5, g6):
+        fn()

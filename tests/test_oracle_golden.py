@@ -1,0 +1,125 @@
+"""Pin the oracle (oracle/njode_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py): forward paths, loss, gradients,
+Adam steps and the known answers of the reference's shipped checkpoints.
+
+Tolerances: same ATen CPU ops as the reference => 1e-6 abs on paths,
+1e-6 rel on loss."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, all_model_cases
+from njode_amd import data_utils, stock_model
+from oracle import njode_oracle
+
+
+def _params(g, requires_grad=False):
+    return {k: v.clone().requires_grad_(requires_grad) for k, v in g.state_dict().items()}
+
+
+def _fwd(g, model, params, **kw):
+    b = g.batch()
+    return model.forward(params, b['times'], b['time_ptr'], b['X'], b['obs_idx'],
+                         g.delta_t, g.T, b['start_X'], b['n_obs_ot'], M=b.get('M'), **kw)
+
+
+@pytest.mark.parametrize('name', all_model_cases())
+def test_eval_forward_matches_reference(name):
+    g = Golden(name)
+    if 'path_y' not in g:
+        pytest.skip('no eval outputs')
+    model = njode_oracle.make_oracle(g.cfg)
+    params = _params(g)
+    assert set(params) == set(model.param_shapes())
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = _fwd(g, model, params, return_path=True,
+                                                get_loss=True, until_T=True)
+    assert np.array_equal(path_t, g['path_t'])
+    np.testing.assert_allclose(path_y.numpy(), g['path_y'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(hT.numpy(), g['hT'], atol=1e-6, rtol=0)
+    if 'path_h' in g:
+        np.testing.assert_allclose(path_h.numpy(), g['path_h'], atol=1e-6, rtol=0)
+    assert float(loss) == pytest.approx(float(g['loss']), rel=1e-6)
+    if 'loss_lastobs' in g:
+        with torch.no_grad():
+            hT2, loss2 = _fwd(g, model, params)
+        np.testing.assert_allclose(hT2.numpy(), g['hT_lastobs'], atol=1e-6, rtol=0)
+        assert float(loss2) == pytest.approx(float(g['loss_lastobs']), rel=1e-6)
+
+
+@pytest.mark.parametrize('name', [n for n in all_model_cases() if not n.startswith('g1_')])
+def test_gradients_match_reference(name):
+    g = Golden(name)
+    model = njode_oracle.make_oracle(g.cfg)
+    model.training = True
+    params = _params(g, requires_grad=True)
+    _, loss = _fwd(g, model, params)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g['train_loss']), rel=1e-6)
+    for k, ref in g.group('grad').items():
+        got = params[k].grad.numpy()
+        denom = max(np.linalg.norm(ref), 1e-12)
+        assert np.linalg.norm(got - ref) / denom < 1e-5, k
+
+
+def test_adam_steps_match_reference():
+    g = Golden('g2_bs_grads_B64')
+    model = njode_oracle.make_oracle(g.cfg)
+    params = _params(g, requires_grad=True)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3, weight_decay=0.0005)
+    b = g.batch()
+    losses = []
+    for step in range(1, 6):
+        losses.append(float(njode_oracle.train_step(model, params, opt, b, g.delta_t, g.T)))
+        if step in (1, 5):
+            for k, ref in g.group('adam{}'.format(step)).items():
+                np.testing.assert_allclose(params[k].detach().numpy(), ref, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(losses, g['adam_losses'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('tag,name', [('BS', 'BlackScholes'), ('Heston', 'Heston'),
+                                      ('OU', 'OrnsteinUhlenbeck')])
+def test_shipped_checkpoint_known_answers(tag, name):
+    """Reference's pre-trained weights (data/saved_models/id-{1,2,3}) on the N=200
+    seed-0 dataset: eval loss, optimal loss, mean-square distance to the analytic
+    conditional expectation."""
+    g = Golden('g3_ckpt_' + tag)
+    hp = copy.deepcopy(data_utils.hyperparam_default)
+    hp['nb_paths'] = 200
+    paths, obs, nb_obs, meta = data_utils.create_dataset(name, hp, seed=0)
+    b = data_utils.collate_arrays(paths, obs, nb_obs, meta['dt'])
+    model = njode_oracle.make_oracle(g.cfg)
+    model.weight = float(g['ckpt_weight'])
+    params = _params(g)
+    dt, T = meta['dt'], meta['maturity']
+    with torch.no_grad():
+        _, loss = model.forward(params, b['times'], b['time_ptr'], b['X'], b['obs_idx'],
+                                dt, T, b['start_X'], b['n_obs_ot'])
+        _, _, path_t, _, path_y = model.forward(
+            params, b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt, T, b['start_X'],
+            None, return_path=True, get_loss=False, until_T=True)
+    sm = stock_model.STOCK_MODELS[name](**meta)
+    opt = sm.get_optimal_loss(b['times'], b['time_ptr'], b['X'].numpy(), b['obs_idx'].numpy(),
+                              dt, T, b['start_X'].numpy(), b['n_obs_ot'].numpy(),
+                              weight=model.weight)
+    _, true_t, true_y = sm.compute_cond_exp(
+        b['times'], b['time_ptr'], b['X'].numpy(), b['obs_idx'].numpy(), dt, T,
+        b['start_X'].numpy(), b['n_obs_ot'].numpy())
+    msd = np.mean((path_y.numpy() - true_y) ** 2)
+    assert np.array_equal(path_t, true_t)
+    assert float(loss) == pytest.approx(float(g['eval_loss']), rel=1e-6)
+    assert opt == pytest.approx(float(g['optimal_loss']), rel=1e-9)
+    assert msd == pytest.approx(float(g['msd_cond_exp']), rel=1e-5)
+    # the published triples, 6 significant digits
+    published = {'BS': (0.127896, 0.118620, 0.0053426), 'Heston': (19.3631, 19.8873, 0.105416),
+                 'OU': (0.00782198, 0.00636915, 0.00062594)}[tag]
+    assert float(loss) == pytest.approx(published[0], rel=2e-5)
+    assert opt == pytest.approx(published[1], rel=2e-5)
+    assert msd == pytest.approx(published[2], rel=2e-5)
+
+
+def test_residual_size_check():
+    with pytest.raises(ValueError):
+        njode_oracle.OracleNJODE(41, 50, 41, None, None, None)
