@@ -1,0 +1,227 @@
+"""
+bench.py -- paths/sec of one NJ-ODE training step (BASELINE.json's metric).
+
+Workload at N = 1 (BASELINE.json configs[1]): 20 000 synthetic Black-Scholes paths
+(stock_model.py hyper-parameters of demo.py: drift 2, vol 0.3, 100 grid steps,
+obs_perc 0.1, seed = rank), model = demo.py constants (hidden 10, three 50-50 tanh
+nets, dropout 0.1, train mode, residual, standard loss).  One "step" = one optimizer
+step over all 20 000 paths of this rank as ONE batch:
+    batch plan + forward + loss + exact backward (HIP kernels)
+    + [N > 1: RCCL all-reduce of the flat gradient, P = 10 071 floats]
+    + Adam(lr 1e-3, weight_decay 5e-4) on the flat parameter vector.
+Inputs (start_X, X, obs_idx, n_obs_ot) are resident in HBM before the timed region.
+N > 1: every rank holds its own 20 000 paths (weak scaling), loss normalised by the
+global batch, one gradient all-reduce per step.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NN = ((50, 'tanh'), (50, 'tanh'))
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VALU_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def model_cfg(dropout):
+    return dict(input_size=1, hidden_size=10, output_size=1, ode_nn=NN, readout_nn=NN,
+                enc_nn=NN, use_rnn=False, bias=True, dropout_rate=dropout,
+                options={'device_outputs': True, 'which_loss': 'standard',
+                         'residual_enc_dec': True})
+
+
+def make_batch(n_paths, seed):
+    from njode_amd import data_utils
+    hp = copy.deepcopy(data_utils.hyperparam_default)
+    hp['nb_paths'] = n_paths
+    paths, obs, nb_obs, meta = data_utils.create_dataset('BlackScholes', hp, seed=seed)
+    return data_utils.collate_arrays(paths, obs, nb_obs, meta['dt']), meta
+
+
+def flops_per_batch(b, n_hidden_units=50, d=1, H=10):
+    """Useful FLOPs of one training step: per Euler step the ODE net,
+    per observation readout-before + encoder + readout-after; backward = 2x forward."""
+    W = n_hidden_units
+    ode = (d + H + 2) * W + W * W + W * H
+    enc = d * W + W * W + W * H
+    dec = H * W + W * W + W * d
+    n_obs = int(b['time_ptr'][-1])
+    B = b['start_X'].shape[0]
+    # Euler steps actually needed: up to each path's last observation
+    last = np.zeros(B, dtype=np.int64)
+    obs = b['observed_dates'][:, 1:]
+    has = obs.any(axis=1)
+    last[has] = obs.shape[1] - np.argmax(obs[has, ::-1], axis=1)
+    steps = int(last.sum())
+    fwd = 2 * (steps * ode + n_obs * (2 * dec + enc) + B * enc)
+    return 3 * fwd, steps, n_obs
+
+
+def cpu_baseline(meta_dt, T, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference, plain PyTorch) timed on this
+    node's host cores on a bounded sample of the same workload: full training steps
+    (forward + backward + Adam, dropout 0.1) at the reference's batch size 200 and at
+    a 4 000-path batch; the better of the two is reported."""
+    from oracle import njode_oracle
+    cfg = model_cfg(0.1)
+    o = njode_oracle.make_oracle(cfg)
+    torch.manual_seed(0)
+    params = {k: v.clone().requires_grad_(True) for k, v in o.init_params(0).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3, weight_decay=0.0005)
+    results = {}
+    t_start = time.perf_counter()
+    for bsz, max_steps in ((200, 24), (4000, 3)):
+        b, _ = make_batch(bsz, seed=1234)
+        njode_oracle.train_step(o, params, opt, b, meta_dt, T)      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < max_steps and time.perf_counter() - t_start < seconds_budget:
+            njode_oracle.train_step(o, params, opt, b, meta_dt, T)
+            n += 1
+        dt = time.perf_counter() - t0
+        if n:
+            results[bsz] = (bsz * n / dt, n)
+    best = max(results, key=lambda k: results[k][0])
+    sample = '; '.join('{} steps of B={} -> {:.0f} paths/s'.format(results[k][1], k, results[k][0])
+                       for k in sorted(results))
+    return {'value': round(results[best][0], 1), 'unit': 'paths/s',
+            'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle train step (fwd+bwd+Adam, dropout 0.1) on synthetic '
+                      'Black-Scholes batches: ' + sample,
+            'host_cpu_count': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--paths-per-gpu', type=int, default=20000)
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
+    if args.gpus > 1 and not distributed:
+        raise SystemExit('launch N > 1 with torch.distributed.run (one rank per GPU)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if distributed:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', device_id=dev)
+
+    from njode_amd import _lib, models
+
+    B = args.paths_per_gpu
+    b, meta = make_batch(B, seed=rank)
+    dt, T = meta['dt'], meta['maturity']
+    torch.manual_seed(0)                       # identical init on every rank
+    model = models.NJODE(**model_cfg(args.dropout)).to(dev).train()
+    model.dp_global_batch = B * world
+    model.dp_path_offset = B * rank
+    opt = models.FusedAdam(model, lr=1e-3, weight_decay=0.0005, distributed=distributed)
+    # inputs resident in HBM before the timed region
+    X, start_X = b['X'].to(dev), b['start_X'].to(dev)
+    obs_idx = b['obs_idx'].to(dev, torch.int32)
+    n_obs_ot = b['n_obs_ot'].to(dev, torch.int32)
+    step_args = (b['times'], b['time_ptr'], X, obs_idx, dt, T, start_X, n_obs_ot)
+
+    def step():
+        _, loss = model.loss_and_grad(*step_args)
+        opt.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timing = not args.no_kernel_timing
+    sync()
+    if timing:
+        _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern = {}
+    if timing:
+        _lib.profile_enable(False)
+        kern = _lib.profile_read()
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if distributed:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = B * world * args.steps / elapsed
+        flops, euler_steps, n_obs = flops_per_batch(b)
+        out = {
+            'metric': 'paths/sec (training step) on 20k Black-Scholes, 100 steps',
+            'value': round(value, 1), 'unit': 'paths/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BlackScholes {} paths/GPU x 100 grid steps as one batch, '
+                                   'hidden_size=10, 3x(50,50) tanh nets, dropout {}, train step '
+                                   '= plan+fwd+bwd+{}Adam'.format(
+                                       B, args.dropout, 'RCCL all-reduce+' if distributed else ''),
+                       'global_batch': B * world, 'n_obs_rows': n_obs,
+                       'euler_steps_per_batch': euler_steps, 'params': 10071,
+                       'parallelism': 'dp{}'.format(world)},
+            'final_loss': final_loss,
+        }
+        if kern:
+            per = {k: round(v[1] / max(v[0], 1), 5) for k, v in kern.items()}
+            out['kernel_ms'] = per
+            dom = max(kern, key=lambda k: kern[k][1])
+            dom_ms = kern[dom][1] / max(kern[dom][0], 1)
+            H = 10
+            # algorithmic HBM bytes of the dominant launch:
+            # k_ode_bwd_items reads every saved state (H f32 per Euler step), per item
+            # lam_end + lam_start (2 H f32) and ~32 B of descriptors / x
+            alg = {'k_ode_bwd_items': euler_steps * H * 4 + n_obs * (2 * H * 4 + 32),
+                   'k_ode_fwd_items': euler_steps * H * 4 + n_obs * (2 * H * 4 + 32),
+                   }.get(dom, euler_steps * H * 4)
+            gbs = alg / (dom_ms * 1e-3) / 1e9
+            out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 3),
+                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': round(gbs / HBM_PEAK_GBS, 6), 'traffic': None,
+                               'kernel_ms': round(dom_ms, 5), 'algorithmic_bytes': int(alg)}
+            tf = flops / (ms * 1e-3) / 1e12
+            out['valu_roofline'] = {'bound': 'fp32-valu', 'achieved': round(tf, 3),
+                                    'peak': FP32_VALU_PEAK_TF, 'unit': 'TFLOP/s',
+                                    'frac': round(tf / FP32_VALU_PEAK_TF, 5),
+                                    'useful_flops_per_step': int(flops)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(dt, T)
+        print(json.dumps(out))
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,195 @@
+/*
+ * njode_hip.h -- C ABI of libnjode_hip.so: the MI355X (gfx950) NJ-ODE hot path.
+ *
+ * The reference (HerreraKrachTeichmann/NJODE) has no native code; its hot path is
+ * the Python method NJODE.forward (NJODE/models.py:379-518) plus autograd's
+ * backward and torch.optim.Adam (NJODE/train.py:397-398, 510-523).  This library
+ * is what a native replacement of that path exports.  Each entry point names the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / STL types.
+ *   - every pointer except `NjodeDims*`, `NjodeSchedule` host arrays and
+ *     `size_t* out` is a DEVICE pointer; the caller owns every buffer.  The
+ *     library allocates nothing persistent and keeps no global state except a
+ *     thread-local error string.
+ *   - all work is enqueued on the caller's `hipStream_t`; nothing synchronises.
+ *   - return 0 on success, an NJODE_E_* code otherwise (message via
+ *     njode_last_error()).  No exceptions cross the ABI.
+ *   - float data is fp32; indices are int32.
+ *
+ * Parameter vector (`params`, `grad_params`): one flat fp32 vector holding the
+ * three networks in the reference's state_dict order (models.py:343-352;
+ * SURVEY.md section 8 a12):
+ *     ode_f.f.{0,3,6}.{weight,bias}, encoder_map.ffnn.{0,3,6}.{weight,bias},
+ *     readout_map.ffnn.{0,3,6}.{weight,bias}
+ * each weight in nn.Linear layout [out][in] row-major, each bias [out].  With
+ * `bias=False` the bias slots are present and must be zero.
+ */
+#ifndef NJODE_HIP_H
+#define NJODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* njodeStream_t; /* == hipStream_t */
+
+/* ---- error codes ----------------------------------------------------------- */
+#define NJODE_OK 0
+#define NJODE_E_UNSUPPORTED 1 /* no gfx950 specialisation for these dims/flags  */
+#define NJODE_E_BADARG 2      /* null pointer / negative size / bad flag combo  */
+#define NJODE_E_WORKSPACE 3   /* workspace too small                            */
+#define NJODE_E_HIP 4         /* a HIP call or launch failed                    */
+
+/* ---- model description (NJODE.__init__, models.py:284-362) ----------------- */
+#define NJODE_ACT_TANH 0
+#define NJODE_ACT_RELU 1
+
+#define NJODE_F_MASKED 0x1           /* options['masked']           models.py:339-341 */
+#define NJODE_F_INPUT_CURRENT_T 0x2  /* options['input_current_t']  models.py:334-337 */
+#define NJODE_F_RESIDUAL 0x4         /* options['residual_enc_dec'] models.py:329-332 */
+#define NJODE_F_LOSS_EASY 0x8        /* which_loss == 'easy'        models.py:109-126 */
+
+typedef struct NjodeDims {
+  int32_t input_size;  /* d                                                      */
+  int32_t hidden_size; /* H                                                      */
+  int32_t output_size; /* d_out                                                  */
+  int32_t n_hidden;    /* hidden layers of each of the three nets (len(nn_desc)) */
+  int32_t width;       /* width of those hidden layers (ignored if n_hidden==0)  */
+  int32_t act;         /* NJODE_ACT_*                                            */
+  int32_t flags;       /* NJODE_F_*                                              */
+} NjodeDims;
+
+/* ---- per-call options ------------------------------------------------------- */
+#define NJODE_C_TRAIN 0x1       /* model.train(): dropout active                  */
+#define NJODE_C_GET_LOSS 0x2    /* get_loss=True                                  */
+#define NJODE_C_RETURN_PATH 0x4 /* return_path=True                               */
+#define NJODE_C_SAVE_BWD 0x8    /* keep what njode_backward_f32 needs in workspace */
+
+/*
+ * Time grid of one forward pass: the float64 clock of NJODE.forward
+ * (models.py:430-439, 497-505) evaluated on the host and rounded exactly as
+ * ATen rounds it (python-float operands are cast to fp32).  HOST arrays; the
+ * library copies them to the device workspace asynchronously, so they must stay
+ * valid until the stream has passed the call (use pinned memory).
+ */
+typedef struct NjodeSchedule {
+  int32_t n_steps;        /* K: Euler steps in this pass (incl. the until_T tail)    */
+  int32_t n_times;        /* number of observation times (len(times))                */
+  const float* step_dt;   /* [K]  fp32(delta_t_k)                                    */
+  const float* step_t;    /* [K]  fp32(current_time before step k)                   */
+  const int32_t* k_jump;  /* [n_times] Euler steps completed before jump i happens   */
+  const float* time_f32;  /* [n_times] fp32(times[i])  (the value written to tau)    */
+  const int32_t* time_ptr;/* [n_times+1] CSR offsets into X / obs_idx (models.py:449)*/
+} NjodeSchedule;
+
+/* One batch in the layout of data_utils.custom_collate_fn (data_utils.py:278-316). */
+typedef struct NjodeBatch {
+  int32_t batch_size;      /* B: paths held by this call (this rank's shard)         */
+  int32_t n_obs;           /* rows of X / obs_idx                                     */
+  const float* start_X;    /* [B, d]                                                  */
+  const float* X;          /* [n_obs, d]  sorted by time, then path                   */
+  const float* M;          /* [n_obs, d]  0/1 mask, or NULL (required iff MASKED)     */
+  const int32_t* obs_idx;  /* [n_obs]     path index of each row                      */
+  const int32_t* n_obs_ot; /* [B] observations per path, or NULL if !GET_LOSS         */
+  float loss_batch_size;   /* the `batch_size` in compute_loss (models.py:106); for a */
+                           /* data-parallel shard pass the GLOBAL batch size          */
+  int64_t path_id_offset;  /* global id of path 0 (dropout streams are keyed by it)   */
+} NjodeBatch;
+
+/* ---- queries ----------------------------------------------------------------- */
+
+/* 1 if this build has a gfx950 specialisation for `dims`, else 0. */
+int njode_supported(const NjodeDims* dims);
+
+/* Length P of the flat parameter vector for `dims` (0 if unsupported). */
+size_t njode_param_count(const NjodeDims* dims);
+
+/* Bytes of workspace njode_forward_f32 / njode_backward_f32 need for a batch of
+ * this size (upper bound; n_steps/n_times as in NjodeSchedule). */
+int njode_workspace_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_obs,
+                          int32_t n_times, int32_t n_steps, int32_t call_flags,
+                          size_t* out);
+
+/* ---- the hot path ------------------------------------------------------------ */
+
+/*
+ * Replaces NJODE.forward (models.py:379-518): encoder -> Euler ODE-evolve between
+ * observation times -> jump at observations -> readout -> paper loss
+ * (models.py:71-126).
+ *
+ *   hT       [B, H]            hidden state at the end of the pass
+ *   loss     [1]               (written iff GET_LOSS) sum over this shard's rows
+ *   path_h   [n_rows, B, H]    (iff RETURN_PATH) n_rows = 1 + n_steps + n_times
+ *   path_y   [n_rows, B, d_out]
+ *
+ * Two execution plans, chosen by the library:
+ *   - segment plan (unmasked, no RETURN_PATH, schedule ends at the last
+ *     observation): every (path, inter-observation segment) is an independent
+ *     work item; items are sorted by length and run one per lane.
+ *   - lockstep plan (everything else): one lane per path over the shared grid,
+ *     jumps applied under a wave ballot.
+ * `weight` is NJODE.weight (models.py:316), `dropout_p` the dropout rate,
+ * `seed` the dropout stream seed (only read when TRAIN and dropout_p > 0).
+ */
+int njode_forward_f32(const NjodeDims* dims, const float* params,
+                      const NjodeBatch* batch, const NjodeSchedule* sched,
+                      int32_t call_flags, float weight, float dropout_p,
+                      uint64_t seed, float* hT, float* loss, float* path_h,
+                      float* path_y, void* workspace, size_t workspace_bytes,
+                      njodeStream_t stream);
+
+/*
+ * Replaces loss.backward() (train.py:522) for the graph NJODE.forward built:
+ * the exact discrete adjoint of the Euler/jump recursion.  Must follow a
+ * njode_forward_f32 call with NJODE_C_SAVE_BWD | NJODE_C_GET_LOSS on the same
+ * workspace, batch, schedule, params, weight, dropout_p and seed.
+ *
+ *   grad_loss    [1]   upstream gradient of the scalar loss (device)
+ *   grad_params  [P]   OVERWRITTEN with d loss / d params * grad_loss
+ *
+ * Round-1 coverage: the segment plan (unmasked, use_rnn=False).  Returns
+ * NJODE_E_UNSUPPORTED for the lockstep plan.
+ */
+int njode_backward_f32(const NjodeDims* dims, const float* params,
+                       const NjodeBatch* batch, const NjodeSchedule* sched,
+                       int32_t call_flags, float weight, float dropout_p,
+                       uint64_t seed, const float* grad_loss, float* grad_params,
+                       void* workspace, size_t workspace_bytes,
+                       njodeStream_t stream);
+
+/*
+ * Replaces torch.optim.Adam(lr, betas, eps, weight_decay).step() on the flat
+ * parameter vector (train.py:397-398, 523): L2 weight decay folded into the
+ * gradient, bias-corrected moments, `step` = 1-based step count.
+ * `grad_scale` multiplies the gradient first (e.g. 1 for summed DP shards).
+ */
+int njode_adam_step_f32(float* params, const float* grad, float* exp_avg,
+                        float* exp_avg_sq, size_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int32_t step,
+                        float grad_scale, njodeStream_t stream);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* njode_last_error(void);
+
+/*
+ * Measurement aid (not part of the replaced reference surface): when enabled,
+ * every hot-path kernel launch is bracketed by hipEvents recorded on the launch
+ * stream.  njode_profile_read synchronises the device and writes one line per
+ * kernel, "<name> <launches> <total_ms>\n", then clears the records.  This is the
+ * library's only process-global state.
+ */
+int njode_profile_enable(int on);
+int njode_profile_read(char* out, size_t cap);
+
+/* Build information: "gfx950;<list of compiled specialisations>". */
+const char* njode_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NJODE_HIP_H */

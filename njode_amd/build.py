@@ -1,0 +1,146 @@
+"""
+Build libnjode_hip.so (gfx950) in-tree with hipcc.
+
+The kernels keep each lane's activations in registers, so every model *shape*
+is a separate template instantiation.  ``CONFIGS`` is the table of compiled
+shapes; ``NJODE_EXTRA_CONFIGS`` (env, ``;``-separated
+``d,H,d_out,n_hidden,width,act,masked,current_t,residual``) appends to it.
+Each shape is compiled as three translation units (segment forward, segment
+backward, lockstep forward) so the build parallelises over the host cores.
+
+Usage:  python -m njode_amd.build [--force] [-j N]
+"""
+import argparse
+import concurrent.futures
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(HERE, 'libnjode_hip.so')
+ARCH = 'gfx950'
+
+TANH, RELU = 0, 1
+# (d, H, d_out, n_hidden, width, act, masked, input_current_t, residual)
+CONFIGS = [
+    (1, 10, 1, 2, 50, TANH, 0, 0, 1),    # demo.py: BlackScholes / OU / Heston (configs 1-4)
+    (1, 10, 1, 2, 50, TANH, 0, 1, 1),    # options['input_current_t']
+    (1, 10, 1, 2, 50, TANH, 0, 0, 0),    # options['residual_enc_dec'] = False
+    (2, 10, 2, 2, 50, TANH, 0, 0, 1),    # func_appl_X=['power-2']
+    (1, 10, 1, 2, 20, RELU, 0, 0, 1),    # relu nets
+    (1, 10, 1, 0, 0, TANH, 0, 0, 1),     # nn_desc=None (single Linear per net)
+    (41, 41, 41, 2, 50, TANH, 1, 0, 1),  # PhysioNet shape, reference setting (H=41 residual)
+    (41, 50, 41, 2, 50, TANH, 1, 0, 0),  # PhysioNet shape, BASELINE config 5 wording (H=50)
+]
+
+
+def all_configs():
+    cfgs = list(CONFIGS)
+    extra = os.environ.get('NJODE_EXTRA_CONFIGS', '').strip()
+    for item in filter(None, extra.split(';')):
+        t = tuple(int(x) for x in item.split(','))
+        if len(t) != 9:
+            raise ValueError('NJODE_EXTRA_CONFIGS entries need 9 integers: ' + item)
+        if t not in cfgs:
+            cfgs.append(t)
+    return cfgs
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def _digest(files, extra=''):
+    h = hashlib.sha256()
+    for path in files:
+        with open(path, 'rb') as f:
+            h.update(os.path.basename(path).encode())
+            h.update(f.read())
+    h.update(extra.encode())
+    return h.hexdigest()
+
+
+def _run(cmd):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        raise RuntimeError('command failed: {}\n{}'.format(' '.join(cmd), p.stdout))
+    return p.stdout
+
+
+def build(force=False, jobs=None, verbose=True):
+    cfgs = all_configs()
+    os.makedirs(OBJ, exist_ok=True)
+    inc = ''.join('NJ_CFG({})\n'.format(i) for i in range(len(cfgs)))
+    inc_path = os.path.join(CSRC, '_generated_cfgs.inc')
+    if not os.path.exists(inc_path) or open(inc_path).read() != inc:
+        with open(inc_path, 'w') as f:
+            f.write(inc)
+    cc = _hipcc()
+    common = [cc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c']
+    hdr = os.path.join(os.path.dirname(HERE), 'include', 'njode_hip.h')
+    kernel_deps = [os.path.join(CSRC, n) for n in
+                   ('njode_cfg.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h')] + [hdr]
+    api_deps = [os.path.join(CSRC, n) for n in
+                ('njode_api.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
+                 '_generated_cfgs.inc')] + [hdr]
+    tasks = []   # (object, command, digest)
+    for i, (d, h, do, nh, w, act, masked, curt, res) in enumerate(cfgs):
+        for part in range(3):
+            obj = os.path.join(OBJ, 'cfg{}_{}.o'.format(i, part))
+            defs = ['-DNJ_ID={}'.format(i), '-DNJ_PART={}'.format(part), '-DNJ_D={}'.format(d),
+                    '-DNJ_H={}'.format(h), '-DNJ_DO={}'.format(do), '-DNJ_NH={}'.format(nh),
+                    '-DNJ_W={}'.format(max(w, 1)), '-DNJ_ACT={}'.format(act),
+                    '-DNJ_MASKED={}'.format(masked), '-DNJ_CURT={}'.format(curt),
+                    '-DNJ_RES={}'.format(res)]
+            cmd = common + defs + [os.path.join(CSRC, 'njode_cfg.hip'), '-o', obj]
+            tasks.append((obj, cmd, _digest(kernel_deps, ' '.join(cmd))))
+    api_obj = os.path.join(OBJ, 'api.o')
+    cmd = common + [os.path.join(CSRC, 'njode_api.hip'), '-o', api_obj]
+    tasks.append((api_obj, cmd, _digest(api_deps, ' '.join(cmd))))
+
+    def stale(t):
+        stamp = t[0] + '.stamp'
+        return (force or not os.path.exists(t[0]) or not os.path.exists(stamp)
+                or open(stamp).read() != t[2])
+
+    todo = [t for t in tasks if stale(t)]
+    if not todo and os.path.exists(LIB) and not force:
+        if verbose:
+            print('[njode_amd.build] up to date:', LIB)
+        return LIB
+    jobs = jobs or int(os.environ.get('NJODE_BUILD_JOBS', os.cpu_count() or 4))
+    if verbose:
+        print('[njode_amd.build] compiling {} of {} units for {} with {} jobs ...'.format(
+            len(todo), len(tasks), ARCH, jobs))
+
+    def compile_one(t):
+        out = _run(t[1])
+        with open(t[0] + '.stamp', 'w') as f:
+            f.write(t[2])
+        return out
+
+    # heaviest units first (masked 41-dim lockstep kernels dominate the wall time)
+    todo.sort(key=lambda t: 0 if t[0].endswith('_2.o') else 1)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for out in ex.map(compile_one, todo):
+            if out.strip() and verbose:
+                print(out)
+    _run([cc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [t[0] for t in tasks])
+    if verbose:
+        print('[njode_amd.build] built', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('-j', type=int, default=None)
+    args = ap.parse_args()
+    build(force=args.force, jobs=args.j)
+    sys.exit(0)

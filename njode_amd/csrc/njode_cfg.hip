@@ -1,0 +1,111 @@
+// njode_cfg.hip -- one model shape, compiled once per entry of the build table
+// (njode_amd/build.py) and per NJ_PART (0 segment forward + registration,
+// 1 segment backward, 2 lockstep forward) with
+//   -DNJ_ID=.. -DNJ_D=.. -DNJ_H=.. -DNJ_DO=.. -DNJ_NH=.. -DNJ_W=.. -DNJ_ACT=..
+//   -DNJ_MASKED=.. -DNJ_CURT=.. -DNJ_RES=.. -DNJ_PART=..
+#include "njode_host.h"
+
+#define NJ_CAT_(a, b) a##b
+#define NJ_CAT(a, b) NJ_CAT_(a, b)
+
+namespace njode {
+
+using C = Cfg<NJ_D, NJ_H, NJ_DO, NJ_NH, NJ_W, NJ_ACT, (NJ_MASKED != 0), (NJ_CURT != 0),
+              (NJ_RES != 0)>;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool save, hipStream_t st);
+hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
+hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
+                                             hipStream_t st);
+
+#if NJ_PART == 0
+template <bool DROP> static hipError_t seg_forward_t(const KArgs& a, bool save, hipStream_t st) {
+  if constexpr (C::MASKED) {
+    return hipErrorNotSupported;
+  } else {
+    {
+      ProfScope ps("k_encode_rows", st);
+      k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_ode_fwd_items", st);
+      if (save) k_ode_fwd_items<C, DROP, true><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
+      else k_ode_fwd_items<C, DROP, false><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_jump_rows", st);
+      k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
+    }
+    k_gather_hT<C><<<cdiv(a.B, 256), 256, 0, st>>>(a);
+    return hipGetLastError();
+  }
+}
+hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool save, hipStream_t st) {
+  return drop ? seg_forward_t<true>(a, save, st) : seg_forward_t<false>(a, save, st);
+}
+
+const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
+  static const CfgOps ops = {
+      {NJ_D, NJ_H, NJ_DO, NJ_NH, (NJ_NH > 0 ? NJ_W : 0), NJ_ACT,
+       (NJ_MASKED ? NJODE_F_MASKED : 0) | (NJ_CURT ? NJODE_F_INPUT_CURRENT_T : 0) |
+           (NJ_RES ? NJODE_F_RESIDUAL : 0)},
+      C::P,
+      C::ODE_IN,
+      C::ENC_IN,
+      NJ_CAT(njode_seg_forward_, NJ_ID),
+      NJ_CAT(njode_seg_backward_, NJ_ID),
+      NJ_CAT(njode_lock_forward_, NJ_ID)};
+  return &ops;
+}
+#endif
+
+#if NJ_PART == 1
+template <bool DROP> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
+  if constexpr (C::MASKED) {
+    return hipErrorNotSupported;
+  } else {
+    {
+      ProfScope ps("k_jump_rows_bwd", st);
+      k_jump_rows_bwd<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_ode_bwd_items", st);
+      k_ode_bwd_items<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_encode_rows_bwd", st);
+      k_encode_rows_bwd<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    return hipGetLastError();
+  }
+}
+hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
+  return drop ? seg_backward_t<true>(a, st) : seg_backward_t<false>(a, st);
+}
+#endif
+
+#if NJ_PART == 2
+template <bool DROP, bool PATH, bool LOSS> static hipError_t lock_t(const KArgs& a, hipStream_t st) {
+  ProfScope ps("k_paths_fwd", st);
+  k_paths_fwd<C, DROP, PATH, LOSS><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+  return hipGetLastError();
+}
+hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
+                                             hipStream_t st) {
+  const int sel = (drop ? 4 : 0) | (path ? 2 : 0) | (loss ? 1 : 0);
+  switch (sel) {
+    case 0: return lock_t<false, false, false>(a, st);
+    case 1: return lock_t<false, false, true>(a, st);
+    case 2: return lock_t<false, true, false>(a, st);
+    case 3: return lock_t<false, true, true>(a, st);
+    case 4: return lock_t<true, false, false>(a, st);
+    case 5: return lock_t<true, false, true>(a, st);
+    case 6: return lock_t<true, true, false>(a, st);
+    default: return lock_t<true, true, true>(a, st);
+  }
+}
+#endif
+
+}  // namespace njode

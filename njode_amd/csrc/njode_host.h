@@ -1,0 +1,33 @@
+// njode_host.h -- glue between the per-configuration translation units
+// (njode_cfg.hip, one per compiled model shape) and the C-ABI unit (njode_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/njode_hip.h"
+#include "njode_kernels.h"
+
+namespace njode {
+
+constexpr int MAX_WAVES = 2048;  // persistent gradient kernels: 256 CUs x 8 waves
+
+struct CfgOps {
+  NjodeDims dims;
+  int P;          // flat parameter count
+  int ode_in, enc_in;
+  // segment plan
+  hipError_t (*seg_forward)(const KArgs&, bool drop, bool save, hipStream_t);
+  hipError_t (*seg_backward)(const KArgs&, bool drop, hipStream_t);
+  // lockstep plan
+  hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, hipStream_t);
+};
+
+// Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events
+// recorded on the launch stream around each kernel.  Defined in njode_api.hip.
+void prof_mark(const char* name, hipStream_t st, bool begin);
+struct ProfScope {
+  const char* name;
+  hipStream_t st;
+  ProfScope(const char* n, hipStream_t s) : name(n), st(s) { prof_mark(name, st, true); }
+  ~ProfScope() { prof_mark(name, st, false); }
+};
+
+}  // namespace njode

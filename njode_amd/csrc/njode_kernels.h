@@ -1,0 +1,617 @@
+// njode_kernels.h -- the gfx950 kernels of the NJ-ODE hot path, templated on the
+// model configuration.  Reference semantics: NJODE/models.py:379-518 (forward),
+// :71-126 (loss), :188-199 (ODE rhs), :261-276 (encoder / readout).
+//
+// Two execution plans:
+//   segment plan  : k_encode_rows -> k_ode_fwd_items -> k_jump_rows
+//                   [-> k_jump_rows_bwd -> k_ode_bwd_items -> k_encode_rows_bwd]
+//   lockstep plan : k_paths_fwd
+#pragma once
+#include "njode_device.h"
+
+namespace njode {
+
+constexpr uint32_t NET_ODE = 0, NET_ENC = 1, NET_DEC = 2, NET_DEC_BJ = 3, NET_DEC_ROW = 4;
+constexpr uint32_t TKEY_START = 0xffffffffu;
+
+template <int D_, int H_, int DO_, int NH_, int W_, int ACT_, bool MASKED_, bool CURT_,
+          bool RES_>
+struct Cfg {
+  static constexpr int D = D_, H = H_, DO = DO_, NH = NH_, W = (NH_ > 0 ? W_ : 1), ACT = ACT_;
+  static constexpr bool MASKED = MASKED_, CURT = CURT_, RES = RES_;
+  static constexpr int ODE_IN = D + H + (CURT ? 3 : 2);
+  static constexpr int ENC_IN = MASKED ? 2 * D : D;
+  using Ode = NetL<ODE_IN, H, NH, W_>;
+  using Enc = NetL<ENC_IN, H, NH, W_>;
+  using Dec = NetL<H, DO, NH, W_>;
+  static constexpr int OFF_ODE = 0, OFF_ENC = Ode::SIZE, OFF_DEC = Ode::SIZE + Enc::SIZE;
+  static constexpr int P = OFF_DEC + Dec::SIZE;
+  // residual cases of FFNN (models.py:240-259)
+  static constexpr int ENC_CASE = !RES ? 0 : (D <= H ? 1 : 2);
+  static constexpr int DEC_CASE = !RES ? 0 : (H <= DO ? 1 : 2);
+  static_assert(!RES || (D <= H ? H % D == 0 : D % H == 0), "residual: sizes must divide");
+  static_assert(!RES || (H <= DO ? DO % H == 0 : H % DO == 0), "residual: sizes must divide");
+  static_assert(!MASKED || D == DO, "masked mode imputes X with the readout");
+};
+
+struct KArgs {
+  // parameters: flat vector and its transposed copy (weights stored [in][out])
+  const float* P;
+  const float* PT;
+  // batch
+  int B, n_obs;
+  const float* start_X;
+  const float* X;
+  const float* M;
+  const int* obs_idx;
+  const int* n_obs_ot;
+  float inv_batch;
+  unsigned long long gid0;
+  // schedule (device copies)
+  int K, n_times;
+  const float* step_dt;
+  const float* step_t;
+  const int* k_jump;
+  const float* time_f32;
+  // plan
+  const int* t_of_row;
+  const int* row_by_path;
+  const int* path_sorted;
+  const int* first_j;
+  const int* first_row;
+  const int* last_row;
+  const int* item_prev;
+  const int* item_next;
+  const int* item_kbeg;
+  const int* item_len;
+  const int* order;
+  const long long* base_s;
+  // intermediates
+  float* h0row;
+  float* h0start;
+  float* h_end;
+  float* lam_end;
+  float* g_h0;
+  float* lam_start;
+  float* traj;
+  float* loss_terms;
+  float* slab;
+  float* trash;  // [64 * max(H, D)] scratch target for the stores of inactive lanes
+  int n_waves;
+  // outputs
+  float* hT;
+  float* path_h;
+  float* path_y;
+  // options
+  float weight;
+  int loss_easy;
+  DropCtx dc;
+  float keep;
+};
+
+// ---- small per-lane helpers -------------------------------------------------------
+template <int N> NJ_DEV void load_vec(const float* p, float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = p[i];
+}
+template <int N> NJ_DEV void store_vec(float* p, const float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) p[i] = v[i];
+}
+NJ_DEV int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <class C, bool DROP> struct Masks {
+  uint64_t m1 = 0, m2 = 0;
+  NJ_DEV void draw(const KArgs& a, unsigned long long gid, uint32_t tkey, uint32_t net) {
+    if constexpr (DROP && C::NH > 0) {
+      uint32_t s = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32), tkey, net);
+      m1 = keep_mask<C::W>(s, a.dc.thr16);
+      if constexpr (C::NH > 1) m2 = keep_mask<C::W>(s, a.dc.thr16);
+    }
+  }
+};
+
+// encoder_map (FFNN, models.py:261-276): h = ffnn([tanh(x), mask]) (+ identity)
+template <class C, bool DROP>
+NJ_DEV void encode(cfp Pe, const float (&x)[C::D], const float (&mask)[C::D],
+                   float (&ein)[C::ENC_IN], float (&a1)[C::W], float (&a2)[C::W],
+                   const Masks<C, DROP>& mk, float inv_keep, float (&h)[C::H]) {
+#pragma unroll
+  for (int i = 0; i < C::D; ++i) ein[i] = tanh_f(x[i]);
+  if constexpr (C::MASKED) {
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) ein[C::D + i] = mask[i];
+  }
+  net_fwd<typename C::Enc, C::ACT, DROP>(Pe, ein, h, a1, a2, mk.m1, mk.m2, inv_keep);
+  if constexpr (C::ENC_CASE == 1) {
+#pragma unroll
+    for (int j = 0; j < C::H; ++j) h[j] += x[j % C::D];
+  } else if constexpr (C::ENC_CASE == 2) {
+    constexpr int mult = C::D / C::H;
+#pragma unroll
+    for (int j = 0; j < C::H; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < mult; ++c) s += x[c * C::H + j];
+      h[j] += s * (1.0f / mult);
+    }
+  }
+}
+
+// readout_map: y = ffnn(tanh(h)) (+ identity); th receives tanh(h)
+template <class C, bool DROP>
+NJ_DEV void readout(cfp Pd, const float (&h)[C::H], float (&th)[C::H], float (&a1)[C::W],
+                    float (&a2)[C::W], const Masks<C, DROP>& mk, float inv_keep,
+                    float (&y)[C::DO]) {
+#pragma unroll
+  for (int i = 0; i < C::H; ++i) th[i] = tanh_f(h[i]);
+  net_fwd<typename C::Dec, C::ACT, DROP>(Pd, th, y, a1, a2, mk.m1, mk.m2, inv_keep);
+  if constexpr (C::DEC_CASE == 1) {
+#pragma unroll
+    for (int j = 0; j < C::DO; ++j) y[j] += h[j % C::H];
+  } else if constexpr (C::DEC_CASE == 2) {
+    constexpr int mult = C::H / C::DO;
+#pragma unroll
+    for (int j = 0; j < C::DO; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < mult; ++c) s += h[c * C::DO + j];
+      y[j] += s * (1.0f / mult);
+    }
+  }
+}
+
+// ODE input vector (models.py:188-199)
+template <class C>
+NJ_DEV void ode_input(const float (&tx)[C::D], const float (&h)[C::H], float tau, float t,
+                      float (&in0)[C::ODE_IN]) {
+#pragma unroll
+  for (int i = 0; i < C::D; ++i) in0[i] = tx[i];
+#pragma unroll
+  for (int i = 0; i < C::H; ++i) in0[C::D + i] = tanh_f(h[i]);
+  const float tdiff = t - tau;
+  in0[C::D + C::H] = tau;
+  in0[C::D + C::H + 1] = tdiff;
+  if constexpr (C::CURT) in0[C::D + C::H + 2] = tau + tdiff;
+}
+
+// paper loss of one observation row and its gradients (models.py:71-126)
+template <class C>
+NJ_DEV float loss_row(const float (&x)[C::D], const float (&mask)[C::D], const float (&y)[C::DO],
+                      const float (&ybj)[C::DO], float w, int easy, float scale,
+                      float (&dy)[C::DO], float (&dybj)[C::DO]) {
+  static_assert(C::D == C::DO, "loss compares X with the readout");
+  float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+  for (int q = 0; q < C::D; ++q) {
+    const float m = C::MASKED ? mask[q] : 1.0f;
+    const float e = x[q] - y[q];
+    const float f = easy ? (ybj[q] - x[q]) : (ybj[q] - y[q]);
+    sa = fmaf(m * e, e, sa);
+    sb = fmaf(m * f, f, sb);
+  }
+  const float na = sqrtf(sa + 1e-10f), nb = sqrtf(sb + 1e-10f);
+  const float ca = easy ? w : 2.0f * w, cb = easy ? (1.0f - w) : 2.0f * (1.0f - w);
+  const float s = ca * na + cb * nb;
+  const float g = 2.0f * s * scale;
+  const float ga = g * ca / na, gb = g * cb / nb;
+#pragma unroll
+  for (int q = 0; q < C::D; ++q) {
+    const float m = C::MASKED ? mask[q] : 1.0f;
+    const float e = x[q] - y[q];
+    if (easy) {
+      const float f = ybj[q] - x[q];
+      dy[q] = -ga * m * e;
+      dybj[q] = gb * m * f;
+    } else {
+      const float f = ybj[q] - y[q];
+      dy[q] = -ga * m * e - gb * m * f;
+      dybj[q] = gb * m * f;
+    }
+  }
+  return s * s * scale;
+}
+
+// =====================================================================================
+// Segment plan
+// =====================================================================================
+
+// E: h0 of every segment: encoder on every observation row and every start value.
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64) k_encode_rows(KArgs a) {
+  const int tid = blockIdx.x * 64 + threadIdx.x;
+  const int total = a.n_obs + a.B;
+  if (tid >= total) return;
+  const bool is_row = tid < a.n_obs;
+  const int b = is_row ? a.obs_idx[tid] : tid - a.n_obs;
+  const float* xp = is_row ? a.X + (size_t)tid * C::D : a.start_X + (size_t)b * C::D;
+  float x[C::D], mask[C::D], ein[C::ENC_IN], a1[C::W], a2[C::W], h[C::H];
+  load_vec(xp, x);
+#pragma unroll
+  for (int i = 0; i < C::D; ++i) mask[i] = 0.0f;
+  Masks<C, DROP> mk;
+  mk.draw(a, a.gid0 + b, is_row ? (uint32_t)a.k_jump[a.t_of_row[tid]] : TKEY_START, NET_ENC);
+  encode<C, DROP>(as_cfp(a.P) + C::OFF_ENC, x, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
+  store_vec(is_row ? a.h0row + (size_t)tid * C::H : a.h0start + (size_t)b * C::H, h);
+}
+
+// Per-item descriptor loaded by the ODE kernels (items sorted by length, descending)
+template <class C> struct Item {
+  int r, b, n, kbeg;
+  float tau;
+  float tx[C::D];
+  NJ_DEV void load(const KArgs& a, int j, bool valid) {
+    const int jj = valid ? j : 0;
+    r = a.order[jj];
+    b = a.obs_idx[r];
+    n = valid ? a.item_len[r] : 0;
+    kbeg = a.item_kbeg[r];
+    const int prev = a.item_prev[r];
+    tau = prev >= 0 ? a.time_f32[a.t_of_row[prev]] : 0.0f;
+    const float* xp = prev >= 0 ? a.X + (size_t)prev * C::D : a.start_X + (size_t)b * C::D;
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) tx[i] = tanh_f(xp[i]);
+  }
+  NJ_DEV const float* h0(const KArgs& a) const {
+    const int prev = a.item_prev[r];
+    return prev >= 0 ? a.h0row + (size_t)prev * C::H : a.h0start + (size_t)b * C::H;
+  }
+};
+
+// B: Euler evolve of every segment from its h0 to the state just before its jump.
+template <class C, bool DROP, bool SAVE>
+__global__ void __launch_bounds__(64) k_ode_fwd_items(KArgs a) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const bool valid = j < a.n_obs;
+  Item<C> it;
+  it.load(a, j, valid);
+  float h[C::H];
+  load_vec(it.h0(a), h);
+  const int nmax = wave_max(it.n);
+  const cfp Pbase = as_cfp(a.P) + C::OFF_ODE;
+  for (int s = 0; s < nmax; ++s) {
+    const bool active = s < it.n;
+    const int k = active ? it.kbeg + s : 0;
+    if constexpr (SAVE) {
+      float* dst = active ? a.traj + (size_t)(a.base_s[s] + j) * C::H
+                          : a.trash + threadIdx.x * C::H;
+      store_vec(dst, h);
+    }
+    const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
+    const cfp Po = launder(Pbase);
+    float in0[C::ODE_IN], a1[C::W], a2[C::W], f[C::H];
+    ode_input<C>(it.tx, h, it.tau, t, in0);
+    Masks<C, DROP> mk;
+    mk.draw(a, a.gid0 + it.b, (uint32_t)k, NET_ODE);
+    net_fwd<typename C::Ode, C::ACT, DROP>(Po, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
+#pragma unroll
+    for (int i = 0; i < C::H; ++i) h[i] = fmaf(dt, f[i], h[i]);  // dt == 0 when inactive
+  }
+  store_vec(valid ? a.h_end + (size_t)it.r * C::H : a.trash + threadIdx.x * C::H, h);
+}
+
+// A (forward): readout before and after the jump, loss term of each row.
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64) k_jump_rows(KArgs a) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= a.n_obs) return;
+  const int b = a.obs_idx[r];
+  const uint32_t tkey = (uint32_t)a.k_jump[a.t_of_row[r]];
+  const cfp Pd = as_cfp(a.P) + C::OFF_DEC;
+  float h[C::H], th[C::H], a1[C::W], a2[C::W], y[C::DO], ybj[C::DO], x[C::D], mask[C::D];
+  Masks<C, DROP> mk;
+  load_vec(a.h_end + (size_t)r * C::H, h);
+  mk.draw(a, a.gid0 + b, tkey, NET_DEC_BJ);
+  readout<C, DROP>(Pd, h, th, a1, a2, mk, a.dc.inv_keep, ybj);
+  load_vec(a.h0row + (size_t)r * C::H, h);
+  mk.draw(a, a.gid0 + b, tkey, NET_DEC);
+  readout<C, DROP>(launder(Pd), h, th, a1, a2, mk, a.dc.inv_keep, y);
+  load_vec(a.X + (size_t)r * C::D, x);
+#pragma unroll
+  for (int i = 0; i < C::D; ++i) mask[i] = 1.0f;
+  float dy[C::DO], dybj[C::DO];
+  const float scale = a.inv_batch / (float)a.n_obs_ot[b];
+  a.loss_terms[r] = loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+}
+
+// hT of the segment plan: the state after each path's last jump (or its start value)
+template <class C> __global__ void k_gather_hT(KArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int lr = a.last_row[b];
+  const float* src = lr >= 0 ? a.h0row + (size_t)lr * C::H : a.h0start + (size_t)b * C::H;
+#pragma unroll
+  for (int i = 0; i < C::H; ++i) a.hT[(size_t)b * C::H + i] = src[i];
+}
+
+// Gradient of the readout's identity path + tanh at its input
+template <class C>
+NJ_DEV void readout_input_grad(const float (&din)[C::H], const float (&th)[C::H],
+                               const float (&dy)[C::DO], float (&dh)[C::H]) {
+#pragma unroll
+  for (int i = 0; i < C::H; ++i) dh[i] = din[i] * (1.0f - th[i] * th[i]);
+  if constexpr (C::DEC_CASE == 1) {
+#pragma unroll
+    for (int j = 0; j < C::DO; ++j) dh[j % C::H] += dy[j];
+  } else if constexpr (C::DEC_CASE == 2) {
+    constexpr int mult = C::H / C::DO;
+#pragma unroll
+    for (int i = 0; i < C::H; ++i) dh[i] += dy[i % C::DO] * (1.0f / mult);
+  }
+}
+
+// A (backward): d loss / d readout params; adjoint at the segment end (lam_end) and
+// the loss' direct gradient on the post-jump state (g_h0).
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64, 2) k_jump_rows_bwd(KArgs a) {
+  using NL = typename C::Dec;
+  __shared__ float lds_raw[NetAcc<NL>::LDS_FLOATS];
+  lfp lds = (lfp)lds_raw;
+  const int lane = threadIdx.x;
+  const int wave = blockIdx.x;
+  NetAcc<NL> g;
+  g.zero();
+  const cfp Pd0 = as_cfp(a.P) + C::OFF_DEC, PTd0 = as_cfp(a.PT) + C::OFF_DEC;
+  const int n_tiles = (a.n_obs + 63) / 64;
+  for (int tile = wave; tile < n_tiles; tile += a.n_waves) {
+    const int r0 = tile * 64 + lane;
+    const bool valid = r0 < a.n_obs;
+    const int r = valid ? r0 : 0;
+    const int b = a.obs_idx[r];
+    const unsigned long long gid = a.gid0 + b;
+    const uint32_t tkey = (uint32_t)a.k_jump[a.t_of_row[r]];
+    const cfp Pd = launder(Pd0), PTd = launder(PTd0);
+    float h[C::H], th[C::H], a1[C::W], a2[C::W], y[C::DO], ybj[C::DO], x[C::D], mask[C::D];
+    float dy[C::DO], dybj[C::DO], din[C::H], dh[C::H];
+    Masks<C, DROP> mk_bj, mk;
+    mk_bj.draw(a, gid, tkey, NET_DEC_BJ);
+    mk.draw(a, gid, tkey, NET_DEC);
+    // forward: y_bj first (activations discarded), then y (activations kept)
+    load_vec(a.h_end + (size_t)r * C::H, h);
+    readout<C, DROP>(Pd, h, th, a1, a2, mk_bj, a.dc.inv_keep, ybj);
+    load_vec(a.h0row + (size_t)r * C::H, h);
+    readout<C, DROP>(Pd, h, th, a1, a2, mk, a.dc.inv_keep, y);
+    load_vec(a.X + (size_t)r * C::D, x);
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) mask[i] = 1.0f;
+    // branch-free on purpose: a divergent branch here splits the block and makes the
+    // compiler keep a whole network's scalar-loaded weights live across it
+    const float scale = (valid ? a.inv_batch : 0.0f) * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
+    loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+    // backward through y = readout(h0row[r])
+    net_bwd<NL, C::ACT, DROP, 0, C::H>(PTd, lds, g, th, dy, a1, a2, mk.m1, mk.m2,
+                                       a.dc.inv_keep, a.keep, din, lane);
+    readout_input_grad<C>(din, th, dy, dh);
+    store_vec(valid ? a.g_h0 + (size_t)r * C::H : a.trash + lane * C::H, dh);
+    // backward through y_bj = readout(h_end[r]) (recompute its activations)
+    load_vec(a.h_end + (size_t)r * C::H, h);
+    readout<C, DROP>(launder(Pd), h, th, a1, a2, mk_bj, a.dc.inv_keep, ybj);
+    net_bwd<NL, C::ACT, DROP, 0, C::H>(launder(PTd), lds, g, th, dybj, a1, a2, mk_bj.m1,
+                                       mk_bj.m2, a.dc.inv_keep, a.keep, din, lane);
+    readout_input_grad<C>(din, th, dybj, dh);
+    store_vec(valid ? a.lam_end + (size_t)r * C::H : a.trash + lane * C::H, dh);
+  }
+  g.flush(a.slab + (size_t)wave * C::P + C::OFF_DEC, lane);
+}
+
+// C: reverse Euler sweep of every segment (exact discrete adjoint), d loss / d ODE params.
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64, 2) k_ode_bwd_items(KArgs a) {
+  using NL = typename C::Ode;
+  __shared__ float lds_raw[NetAcc<NL>::LDS_FLOATS];
+  lfp lds = (lfp)lds_raw;
+  const int lane = threadIdx.x;
+  const int wave = blockIdx.x;
+  NetAcc<NL> g;
+  g.zero();
+  const cfp Po0 = as_cfp(a.P) + C::OFF_ODE, PTo0 = as_cfp(a.PT) + C::OFF_ODE;
+  const int n_tiles = (a.n_obs + 63) / 64;
+  for (int tile = wave; tile < n_tiles; tile += a.n_waves) {
+    const int j = tile * 64 + lane;
+    const bool valid = j < a.n_obs;
+    Item<C> it;
+    it.load(a, j, valid);
+    float lam[C::H];
+    load_vec(a.lam_end + (size_t)it.r * C::H, lam);  // r is clamped to a valid row
+#pragma unroll
+    for (int i = 0; i < C::H; ++i) lam[i] = valid ? lam[i] : 0.0f;
+    const int nmax = wave_max(it.n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      float h[C::H];
+      // inactive lanes read slot 0 (always allocated when the loop runs); their
+      // contribution is cancelled by dt = 0 below
+      load_vec(a.traj + (active ? (size_t)(a.base_s[s] + j) * C::H : 0), h);
+      const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
+      const cfp Po = launder(Po0), PTo = launder(PTo0);
+      float in0[C::ODE_IN], a1[C::W], a2[C::W], f[C::H], dout[C::H], din[C::H];
+      ode_input<C>(it.tx, h, it.tau, t, in0);
+      Masks<C, DROP> mk;
+      mk.draw(a, a.gid0 + it.b, (uint32_t)k, NET_ODE);
+      net_fwd<NL, C::ACT, DROP>(Po, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
+      // h' = h + dt f(h): d/df = dt * lam (zero for inactive lanes since dt = 0)
+#pragma unroll
+      for (int i = 0; i < C::H; ++i) dout[i] = dt * lam[i];
+      net_bwd<NL, C::ACT, DROP, C::D, C::D + C::H>(PTo, lds, g, in0, dout, a1, a2, mk.m1,
+                                                   mk.m2, a.dc.inv_keep, a.keep, din, lane);
+#pragma unroll
+      for (int i = 0; i < C::H; ++i) {
+        const float th = in0[C::D + i];
+        lam[i] = fmaf(din[i], 1.0f - th * th, lam[i]);
+      }
+    }
+    store_vec(valid ? a.lam_start + (size_t)it.r * C::H : a.trash + lane * C::H, lam);
+  }
+  g.flush(a.slab + (size_t)wave * C::P + C::OFF_ODE, lane);
+}
+
+// D: d loss / d encoder params from the adjoints at every segment start.
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64, 2) k_encode_rows_bwd(KArgs a) {
+  using NL = typename C::Enc;
+  __shared__ float lds_raw[NetAcc<NL>::LDS_FLOATS];
+  lfp lds = (lfp)lds_raw;
+  const int lane = threadIdx.x;
+  const int wave = blockIdx.x;
+  NetAcc<NL> g;
+  g.zero();
+  const cfp Pe0 = as_cfp(a.P) + C::OFF_ENC, PTe0 = as_cfp(a.PT) + C::OFF_ENC;
+  const int total = a.n_obs + a.B;
+  const int n_tiles = (total + 63) / 64;
+  for (int tile = wave; tile < n_tiles; tile += a.n_waves) {
+    const int t0 = tile * 64 + lane;
+    const bool valid = t0 < total;
+    const int tid = valid ? t0 : 0;
+    const bool is_row = tid < a.n_obs;
+    const int b = is_row ? a.obs_idx[tid] : tid - a.n_obs;
+    const float* xp = is_row ? a.X + (size_t)tid * C::D : a.start_X + (size_t)b * C::D;
+    float x[C::D], mask[C::D], ein[C::ENC_IN], a1[C::W], a2[C::W], h[C::H], gh[C::H], din[1];
+    load_vec(xp, x);
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) mask[i] = 0.0f;
+    {
+      // adjoint of this start state: the next segment's sweep result, plus (for an
+      // observation row) the loss' direct gradient through y = readout(h0).
+      // Branch-free: clamped loads, then selects.
+      const int nxt = is_row ? a.item_next[tid] : a.first_row[b];
+      const int nx = nxt >= 0 ? nxt : 0;
+      const int rr = is_row ? tid : 0;
+#pragma unroll
+      for (int i = 0; i < C::H; ++i) {
+        const float l = a.lam_start[(size_t)nx * C::H + i];
+        const float q = a.g_h0[(size_t)rr * C::H + i];
+        gh[i] = valid ? ((nxt >= 0 ? l : 0.0f) + (is_row ? q : 0.0f)) : 0.0f;
+      }
+    }
+    Masks<C, DROP> mk;
+    mk.draw(a, a.gid0 + b, is_row ? (uint32_t)a.k_jump[a.t_of_row[tid]] : TKEY_START, NET_ENC);
+    encode<C, DROP>(launder(Pe0), x, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
+    net_bwd<NL, C::ACT, DROP, 0, 0>(launder(PTe0), lds, g, ein, gh, a1, a2, mk.m1, mk.m2,
+                                    a.dc.inv_keep, a.keep, din, lane);
+  }
+  g.flush(a.slab + (size_t)wave * C::P + C::OFF_ENC, lane);
+}
+
+// =====================================================================================
+// Lockstep plan: one lane per path over the shared grid (all modes, forward only)
+// =====================================================================================
+template <class C, bool DROP, bool PATH, bool LOSS>
+__global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
+  const int b0 = blockIdx.x * 64 + threadIdx.x;
+  const bool valid = b0 < a.B;
+  const int b = valid ? b0 : a.B - 1;
+  const unsigned long long gid = a.gid0 + b;
+  const cfp Po0 = as_cfp(a.P) + C::OFF_ODE, Pe0 = as_cfp(a.P) + C::OFF_ENC,
+            Pd0 = as_cfp(a.P) + C::OFF_DEC;
+  const cfp kj = as_cfp((const float*)a.k_jump), sdt = as_cfp(a.step_dt),
+            stt = as_cfp(a.step_t), tf = as_cfp(a.time_f32);
+  const int __attribute__((address_space(4)))* kjump =
+      (const int __attribute__((address_space(4)))*)kj;
+
+  float xl[C::D], mask[C::D], h[C::H], y[C::DO];
+  float ein[C::ENC_IN], a1[C::W], a2[C::W], th[C::H];
+  load_vec(a.start_X + (size_t)b * C::D, xl);
+#pragma unroll
+  for (int i = 0; i < C::D; ++i) mask[i] = 0.0f;
+  Masks<C, DROP> mk;
+  mk.draw(a, gid, TKEY_START, NET_ENC);
+  encode<C, DROP>(Pe0, xl, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
+  float tx[C::D];
+#pragma unroll
+  for (int i = 0; i < C::D; ++i) tx[i] = tanh_f(xl[i]);
+  float tau = 0.0f, loss_acc = 0.0f;
+
+  int cur = a.first_j[b];
+  int next_i = a.n_obs > 0 ? a.t_of_row[a.row_by_path[cur >= 0 ? cur : 0]] : 0;
+  next_i = cur >= 0 ? next_i : 0x7fffffff;
+  int row = 0;
+  auto emit = [&](uint32_t tkey) {
+    if constexpr (PATH) {
+      mk.draw(a, gid, tkey, NET_DEC_ROW);
+      readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, y);
+    }
+  };
+  // stores are branch-free (inactive lanes write to a scratch line): a divergent
+  // `if` around the only use of a network's output makes the compiler sink the FMAs
+  // into it and keep the whole network's scalar-loaded weights live (SGPR spills)
+  auto write_row = [&]() {
+    if constexpr (PATH) {
+      store_vec(valid ? a.path_h + ((size_t)row * a.B + b) * C::H : a.trash + threadIdx.x * C::H, h);
+      store_vec(valid ? a.path_y + ((size_t)row * a.B + b) * C::DO
+                      : a.trash + threadIdx.x * C::DO, y);
+      ++row;
+    }
+  };
+  emit(TKEY_START - 1);
+  write_row();
+
+  int i = 0;
+  for (int k = 0;; ++k) {
+    while (i < a.n_times && kjump[i] == k) {
+      const bool has = valid && next_i == i;
+      if (__any(has)) {
+        if (has) {
+          const int r = a.row_by_path[cur];
+          float ybj[C::DO], x[C::D], xin[C::D];
+          mk.draw(a, gid, (uint32_t)k, NET_DEC_BJ);
+          readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, ybj);
+          load_vec(a.X + (size_t)r * C::D, x);
+          if constexpr (C::MASKED) {
+            load_vec(a.M + (size_t)r * C::D, mask);
+#pragma unroll
+            for (int q = 0; q < C::D; ++q)
+              xin[q] = x[q] * mask[q] + (1.0f - mask[q]) * ybj[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < C::D; ++q) { xin[q] = x[q]; mask[q] = 1.0f; }
+          }
+          mk.draw(a, gid, (uint32_t)k, NET_ENC);
+          encode<C, DROP>(launder(Pe0), xin, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
+          mk.draw(a, gid, (uint32_t)k, NET_DEC);
+          readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, y);
+          if constexpr (LOSS) {
+            float dy[C::DO], dybj[C::DO];
+            const float scale = a.inv_batch / (float)a.n_obs_ot[b];
+            loss_acc += loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+          }
+          // last_X <- Y (masked) or X_obs; tau <- obs time (models.py:481-489)
+#pragma unroll
+          for (int q = 0; q < C::D; ++q) tx[q] = tanh_f(C::MASKED ? y[q] : x[q]);
+          tau = tf[i];
+          ++cur;
+          {
+            const int cc = cur < a.n_obs ? cur : 0;
+            const int nt_ = a.t_of_row[a.row_by_path[cc]];
+            next_i = (cur < a.n_obs && a.path_sorted[cc] == b) ? nt_ : 0x7fffffff;
+          }
+        }
+      }
+      write_row();
+      ++i;
+    }
+    if (k >= a.K) break;
+    {
+      const float dt = sdt[k], t = stt[k];
+      float in0[C::ODE_IN], f[C::H];
+      ode_input<C>(tx, h, tau, t, in0);
+      mk.draw(a, gid, (uint32_t)k, NET_ODE);
+      net_fwd<typename C::Ode, C::ACT, DROP>(launder(Po0), in0, f, a1, a2, mk.m1, mk.m2,
+                                             a.dc.inv_keep);
+#pragma unroll
+      for (int q = 0; q < C::H; ++q) h[q] = fmaf(dt, f[q], h[q]);
+      emit(0x80000000u + (uint32_t)k);
+      write_row();
+    }
+  }
+  store_vec(valid ? a.hT + (size_t)b * C::H : a.trash + threadIdx.x * C::H, h);
+  if constexpr (LOSS) {
+    if (valid) a.loss_terms[b] = loss_acc;
+  }
+}
+
+}  // namespace njode

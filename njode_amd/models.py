@@ -1,0 +1,629 @@
+"""
+NJ-ODE model with the operator surface of the reference's ``NJODE/models.py``,
+executed by hand-written HIP kernels for gfx950 (libnjode_hip.so).
+
+Same module-level names, constructor, ``forward`` signature and return
+conventions, ``evaluate`` / ``get_pred`` / ``weight_decay_step``, checkpoint
+helpers and ``state_dict`` keys as the reference (file:line cited per symbol),
+so the class is constructed and called exactly like ``models.NJODE`` is by
+``train.py`` / ``demo.py``.
+
+What is different by construction:
+
+* the sub-modules (``ode_f``, ``encoder_map``, ``readout_map``) only *hold*
+  parameters under the reference's names; their math runs fused inside the
+  kernels, so calling them directly raises.  There is no eager / CPU fallback:
+  a model on a CPU device, or an unbuilt library, raises.
+* all parameters are views of one flat fp32 vector (the layout of the C ABI),
+  so the gradient comes back as one vector and the optimizer step can be fused.
+* ``options['device_outputs']=True`` keeps ``loss`` / predictions on the GPU
+  (no host sync); the default follows the reference harness, which calls
+  ``.numpy()`` on them (``train.py:558,571,726``), and returns CPU tensors.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .schedule import PinnedRing, ScheduleCache
+
+
+# =====================================================================================
+# module-level helpers with the reference's names
+# =====================================================================================
+def init_weights(m, bias=0.0):
+    """Xavier-uniform weights, constant bias (reference ``models.py:21-26``)."""
+    if type(m) == torch.nn.Linear:
+        torch.nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            m.bias.data.fill_(bias)
+
+
+def save_checkpoint(model, optimizer, path, epoch):
+    """``checkpt.tar`` with the reference's keys (``models.py:29-45``)."""
+    if not os.path.exists(path):
+        os.makedirs(path)
+    torch.save({'epoch': epoch, 'weight': model.weight,
+                'model_state_dict': model.state_dict(),
+                'optimizer_state_dict': optimizer.state_dict()},
+               os.path.join(path, 'checkpt.tar'))
+
+
+def get_ckpt_model(ckpt_path, model, optimizer, device):
+    """Load a checkpoint written by this build or by the reference, in place
+    (``models.py:48-66``)."""
+    ckpt_path = os.path.join(ckpt_path, 'checkpt.tar')
+    if not os.path.exists(ckpt_path):
+        raise Exception("Checkpoint " + ckpt_path + " does not exist.")
+    checkpt = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    if optimizer is not None:
+        optimizer.load_state_dict(checkpt['optimizer_state_dict'])
+    model.load_state_dict(checkpt['model_state_dict'])
+    model.epoch = checkpt['epoch']
+    model.weight = checkpt['weight']
+    model.to(device)
+
+
+def _norm(t, dim=1, eps=1e-10):
+    return torch.sqrt(torch.sum(t, dim=dim) + eps)
+
+
+def compute_loss(X_obs, Y_obs, Y_obs_bj, n_obs_ot, batch_size, eps=1e-10,
+                 weight=0.5, M_obs=None):
+    """Paper loss on tensors (reference ``models.py:71-106``).  Utility for
+    callers that hold predictions; the training path computes the same
+    expression inside the kernels."""
+    m = 1.0 if M_obs is None else M_obs
+    after = _norm(m * (X_obs - Y_obs) ** 2, eps=eps)
+    before = _norm(m * (Y_obs_bj - Y_obs) ** 2, eps=eps)
+    inner = (2 * weight * after + 2 * (1 - weight) * before) ** 2
+    return torch.sum(inner / n_obs_ot) / batch_size
+
+
+def compute_loss_2(X_obs, Y_obs, Y_obs_bj, n_obs_ot, batch_size, eps=1e-10,
+                   weight=0.5, M_obs=None):
+    """'easy' variant: second term uses X instead of Y (``models.py:109-126``)."""
+    m = 1.0 if M_obs is None else M_obs
+    after = _norm(m * (X_obs - Y_obs) ** 2, eps=eps)
+    before = _norm(m * (Y_obs_bj - X_obs) ** 2, eps=eps)
+    inner = (weight * after + (1 - weight) * before) ** 2
+    return torch.sum(inner / n_obs_ot) / batch_size
+
+
+LOSS_FUN_DICT = {'standard': compute_loss, 'easy': compute_loss_2}
+
+nonlinears = {'tanh': torch.nn.Tanh, 'relu': torch.nn.ReLU}
+
+
+def get_ffnn(input_size, output_size, nn_desc, dropout_rate, bias):
+    """Parameter container with the reference's Sequential layout
+    (``models.py:140-166``): Linear at indices 0, 3, 6, ... with activation and
+    Dropout modules in between (kept so ``print(model)`` and the state_dict
+    keys match)."""
+    if nn_desc is None:
+        layers = [torch.nn.Linear(input_size, output_size, bias=bias)]
+    else:
+        layers = [torch.nn.Linear(input_size, nn_desc[0][0], bias=bias)]
+        for i in range(len(nn_desc) - 1):
+            layers.append(nonlinears[nn_desc[i][1]]())
+            layers.append(torch.nn.Dropout(p=dropout_rate))
+            layers.append(torch.nn.Linear(nn_desc[i][0], nn_desc[i + 1][0], bias=bias))
+        layers.append(nonlinears[nn_desc[-1][1]]())
+        layers.append(torch.nn.Dropout(p=dropout_rate))
+        layers.append(torch.nn.Linear(nn_desc[-1][0], output_size, bias=bias))
+    return torch.nn.Sequential(*layers)
+
+
+_FUSED_MSG = ('{} holds parameters only: its math runs inside the fused HIP kernels of '
+              'NJODE.forward (libnjode_hip.so); there is no eager path.')
+
+
+class ODEFunc(torch.nn.Module):
+    """f_theta: parameters ``ode_f.f.*`` (reference ``models.py:170-199``)."""
+
+    def __init__(self, input_size, hidden_size, ode_nn, dropout_rate=0.0, bias=True,
+                 input_current_t=False):
+        super().__init__()
+        self.input_current_t = input_current_t
+        add = 3 if input_current_t else 2
+        self.f = get_ffnn(input_size=input_size + hidden_size + add, output_size=hidden_size,
+                          nn_desc=ode_nn, dropout_rate=dropout_rate, bias=bias)
+
+    def forward(self, x, h, tau, tdiff):
+        raise RuntimeError(_FUSED_MSG.format('ODEFunc'))
+
+
+class GRUCell(torch.nn.Module):
+    """rho_theta: parameters ``obs_c.gru_d.*`` (reference ``models.py:202-217``)."""
+
+    def __init__(self, input_size, hidden_size, bias=True):
+        super().__init__()
+        self.gru_d = torch.nn.GRUCell(input_size, hidden_size, bias=bias)
+        self.input_size = input_size
+
+    def forward(self, h, X_obs, i_obs):
+        raise RuntimeError(_FUSED_MSG.format('GRUCell'))
+
+
+class FFNN(torch.nn.Module):
+    """Encoder / readout: parameters ``*.ffnn.*``; residual size rules and error
+    messages of the reference (``models.py:220-276``)."""
+
+    def __init__(self, input_size, output_size, nn_desc, dropout_rate=0.0, bias=True,
+                 residual=False, masked=False):
+        super().__init__()
+        in_size = 2 * input_size if masked else input_size
+        self.masked = masked
+        self.ffnn = get_ffnn(input_size=in_size, output_size=output_size, nn_desc=nn_desc,
+                             dropout_rate=dropout_rate, bias=bias)
+        if residual:
+            print('use residual network: input_size={}, output_size={}'.format(
+                input_size, output_size))
+            if input_size <= output_size:
+                if output_size % input_size == 0:
+                    self.case = 1
+                    self.mult = int(output_size / input_size)
+                else:
+                    raise ValueError('for residual: output_size needs to be '
+                                     'multiple of input_size')
+            if input_size > output_size:
+                if input_size % output_size == 0:
+                    self.case = 2
+                    self.mult = int(input_size / output_size)
+                else:
+                    raise ValueError('for residual: input_size needs to be '
+                                     'multiple of output_size')
+        else:
+            self.case = 0
+
+    def forward(self, nn_input, mask=None):
+        raise RuntimeError(_FUSED_MSG.format('FFNN'))
+
+
+# =====================================================================================
+# autograd bridge
+# =====================================================================================
+class _Call:
+    """Everything one library call needs, kept alive until the stream has used it.
+    Dropping the last reference (e.g. an autograd graph that is never back-propagated)
+    returns the workspace to the model's pool."""
+    __slots__ = ('dims', 'batch', 'sched', 'flags', 'weight', 'p_drop', 'seed', 'ws',
+                 'keep', 'ws_slot')
+
+    def __del__(self):
+        slot = getattr(self, 'ws_slot', None)
+        if slot is not None:
+            slot[1] = False
+
+
+class _NJODEFunction(torch.autograd.Function):
+    """loss = F(params); backward = exact discrete adjoint (njode_backward_f32)."""
+
+    @staticmethod
+    def forward(ctx, model, call, loss, *params):
+        ctx.model = model
+        ctx.call = call
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        model, call = ctx.model, ctx.call
+        grad_flat = torch.empty_like(model._flat)
+        g = grad_loss.to(device=model._flat.device, dtype=torch.float32).reshape(1).contiguous()
+        model._run_backward(call, g, grad_flat)
+        model._release_ws(call)
+        grads = [grad_flat[off:off + n].view(shape) for (off, n, shape) in model._param_slices]
+        return (None, None, None) + tuple(grads)
+
+
+# =====================================================================================
+# the model
+# =====================================================================================
+def _desc_of(nn_desc):
+    """(n_hidden, width, act) if the description fits the kernel family, else None."""
+    if nn_desc is None:
+        return (0, 0, _lib.ACT_TANH)
+    widths = {int(w) for w, _ in nn_desc}
+    acts = {a for _, a in nn_desc}
+    if len(widths) != 1 or len(acts) != 1 or len(nn_desc) > 2:
+        return None
+    act = acts.pop()
+    if act not in nonlinears:
+        raise KeyError(act)
+    return (len(nn_desc), widths.pop(), _lib.ACT_TANH if act == 'tanh' else _lib.ACT_RELU)
+
+
+class NJODE(torch.nn.Module):
+    """NJ-ODE model (reference ``models.py:280-584``), HIP-backed."""
+
+    def __init__(self, input_size, hidden_size, output_size, ode_nn, readout_nn, enc_nn,
+                 use_rnn, bias=True, dropout_rate=0, solver="euler", weight=0.5,
+                 weight_decay=1., **options):
+        super().__init__()
+        self.epoch = 1
+        self.weight = weight
+        self.weight_decay = weight_decay
+        self.use_rnn = use_rnn
+
+        # the harness passes its whole params_dict; the model's own switches sit
+        # under options['options'] (reference models.py:321)
+        options1 = options['options']
+        self.which_loss = options1.get('which_loss', 'standard')
+        assert self.which_loss in LOSS_FUN_DICT
+        print('using loss: {}'.format(self.which_loss))
+        self.residual_enc_dec = options1.get('residual_enc_dec', True)
+        self.input_current_t = options1.get('input_current_t', False)
+        self.masked = options1.get('masked', False)
+        self.device_outputs = bool(options1.get('device_outputs', False))
+
+        self.ode_f = ODEFunc(input_size, hidden_size, ode_nn, dropout_rate, bias,
+                             input_current_t=self.input_current_t)
+        self.encoder_map = FFNN(input_size, hidden_size, enc_nn, dropout_rate, bias,
+                                masked=self.masked, residual=self.residual_enc_dec)
+        self.readout_map = FFNN(hidden_size, output_size, readout_nn, dropout_rate, bias,
+                                residual=self.residual_enc_dec)
+        if self.use_rnn:
+            self.obs_c = GRUCell(input_size, hidden_size, bias=bias)
+
+        self.solver = solver
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.output_size = output_size
+        self.dropout_rate = float(dropout_rate)
+        self.bias = bias
+        self._descs = (_desc_of(ode_nn), _desc_of(enc_nn), _desc_of(readout_nn))
+
+        self.apply(init_weights)
+
+        # data-parallel sharding (set by the harness): global batch size used in the
+        # loss denominator and the global index of this shard's first path
+        self.dp_global_batch = None
+        self.dp_path_offset = 0
+        self.seed = int(options1.get('dropout_seed', 0))
+        self._step_counter = 0
+
+        self._flat = None
+        self._flat_grad = None
+        self._param_slices = None
+        self._flat_params = None
+        self._ones = None
+        self._sched_cache = ScheduleCache()
+        self._ring = None
+        self._ws_pool = []
+        self._dims = None
+
+    # -- reference API ----------------------------------------------------------------
+    def weight_decay_step(self):
+        """weight <- 0.5 + (weight - 0.5) * weight_decay (``models.py:364-367``)."""
+        inc = (self.weight - 0.5)
+        self.weight = 0.5 + inc * self.weight_decay
+        return self.weight
+
+    # -- flat parameter storage -----------------------------------------------------------
+    def _linears(self):
+        mods = []
+        for seq in (self.ode_f.f, self.encoder_map.ffnn, self.readout_map.ffnn):
+            mods += [m for m in seq if isinstance(m, torch.nn.Linear)]
+        return mods
+
+    def _ensure_flat(self):
+        """Make every Linear parameter a view of one flat vector laid out as the C
+        ABI expects (state_dict order; bias slots always present)."""
+        lins = self._linears()
+        dev = lins[0].weight.device
+        total = sum(m.weight.numel() + m.out_features for m in lins)
+        ok = (self._flat is not None and self._flat.device == dev
+              and self._flat.numel() == total)
+        if ok:
+            base = self._flat.data_ptr()
+            for (off, n, _), p in zip(self._param_slices, self._flat_params):
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if ok:
+            return
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        slices, params, off = [], [], 0
+        for m in lins:
+            n = m.weight.numel()
+            flat[off:off + n].copy_(m.weight.data.reshape(-1).to(torch.float32))
+            m.weight.data = flat[off:off + n].view(m.weight.shape)
+            slices.append((off, n, tuple(m.weight.shape)))
+            params.append(m.weight)
+            off += n
+            n = m.out_features
+            if m.bias is not None:
+                flat[off:off + n].copy_(m.bias.data.to(torch.float32))
+                m.bias.data = flat[off:off + n]
+                slices.append((off, n, (n,)))
+                params.append(m.bias)
+            off += n
+        self._flat, self._param_slices, self._flat_params = flat, slices, params
+        self._flat_grad = None
+
+    def flat_parameters(self):
+        """The flat parameter vector all Linear parameters are views of."""
+        self._ensure_flat()
+        return self._flat
+
+    def flat_grad(self):
+        """A flat gradient vector whose slices are installed as ``.grad`` of the
+        parameters (for the fused training step)."""
+        self._ensure_flat()
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+            for (off, n, shape), p in zip(self._param_slices, self._flat_params):
+                p.grad = self._flat_grad[off:off + n].view(shape)
+        return self._flat_grad
+
+    # -- library plumbing ---------------------------------------------------------------
+    def _get_dims(self):
+        if self._dims is not None:
+            return self._dims
+        if self.use_rnn:
+            raise NotImplementedError(
+                'use_rnn=True (GRU jump, reference models.py:202-217) is not implemented '
+                'in the HIP path yet')
+        if self.solver != 'euler':
+            raise ValueError("Unknown solver '{}'.".format(self.solver))
+        if None in self._descs or len(set(self._descs)) != 1:
+            raise NotImplementedError(
+                'the gfx950 kernels are specialised for three networks with the same '
+                'hidden structure (<= 2 hidden layers of one width and activation); got '
+                'ode/enc/readout = {}'.format(self._descs))
+        nh, width, act = self._descs[0]
+        flags = ((_lib.F_MASKED if self.masked else 0)
+                 | (_lib.F_INPUT_CURRENT_T if self.input_current_t else 0)
+                 | (_lib.F_RESIDUAL if self.residual_enc_dec else 0)
+                 | (_lib.F_LOSS_EASY if self.which_loss == 'easy' else 0))
+        d = _lib.NjodeDims(self.input_size, self.hidden_size, self.output_size, nh, width,
+                           act, flags)
+        if not _lib.lib().njode_supported(ctypes.byref(d)):
+            raise NotImplementedError(
+                'libnjode_hip.so has no gfx950 specialisation for input_size={}, '
+                'hidden_size={}, output_size={}, n_hidden={}, width={}, act={}, masked={}, '
+                'input_current_t={}, residual={}.  Add the shape to CONFIGS in '
+                'njode_amd/build.py (or NJODE_EXTRA_CONFIGS) and rebuild.  Compiled: {}'
+                .format(self.input_size, self.hidden_size, self.output_size, nh, width,
+                        act, self.masked, self.input_current_t, self.residual_enc_dec,
+                        _lib.build_info()))
+        self._dims = d
+        return d
+
+    def _acquire_ws(self, nbytes, device):
+        for slot in self._ws_pool:
+            if not slot[1] and slot[0].device == device and slot[0].numel() >= nbytes:
+                slot[1] = True
+                return slot
+        slot = [torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device), True]
+        # keep the pool small: drop free slots that are too small
+        self._ws_pool = [s for s in self._ws_pool if s[1]] + [slot]
+        return slot
+
+    def _release_ws(self, call):
+        if call.ws_slot is not None:
+            call.ws_slot[1] = False
+            call.ws_slot = None
+
+    def _make_call(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
+                   return_path, get_loss, until_T, M, save_bwd):
+        L = _lib.lib()
+        dev = start_X.device
+        if dev.type != 'cuda':
+            raise RuntimeError(
+                'njode_amd.NJODE runs on an MI355X only (inputs are on {}); there is no '
+                'CPU path. Move the model and the batch to a cuda device.'.format(dev))
+        dims = self._get_dims()
+        self._ensure_flat()
+        if self._flat.device != dev:
+            raise RuntimeError('model parameters are on {} but the batch is on {}'.format(
+                self._flat.device, dev))
+        if self._ring is None:
+            self._ring = PinnedRing()
+        B = int(start_X.shape[0])
+        sched = self._sched_cache.get(times, delta_t, T, until_T)
+        time_ptr = np.asarray(time_ptr, dtype=np.int32)
+        assert len(times) + 1 == len(time_ptr)
+        n_obs = int(time_ptr[-1])
+
+        f32 = torch.float32
+        start_X = start_X.to(f32).contiguous()
+        X = X.to(device=dev, dtype=f32).contiguous()
+        obs_idx_d = obs_idx.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
+        keep = [start_X, X, obs_idx_d]
+        M_ptr = None
+        if self.masked:
+            assert M is not None
+            M = M.to(device=dev, dtype=f32).contiguous()
+            keep.append(M)
+            M_ptr = M.data_ptr()
+        n_ptr = None
+        if get_loss:
+            n_d = n_obs_ot.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous()
+            keep.append(n_d)
+            n_ptr = n_d.data_ptr()
+
+        slot_i, pinned = self._ring.acquire(sched.packed_nbytes())
+        buf = pinned.numpy()
+        K, nt = sched.pack_into(buf, time_ptr)
+        base = pinned.data_ptr()
+        cs = _lib.NjodeSchedule(K, nt, base, base + 4 * K, base + 8 * K, base + 8 * K + 4 * nt,
+                                base + 8 * K + 8 * nt)
+        gb = float(self.dp_global_batch if self.dp_global_batch else B)
+        cb = _lib.NjodeBatch(B, n_obs, start_X.data_ptr(), X.data_ptr() if n_obs else None,
+                             M_ptr, obs_idx_d.data_ptr() if n_obs else None, n_ptr, gb,
+                             int(self.dp_path_offset))
+        flags = ((_lib.C_TRAIN if self.training else 0) | (_lib.C_GET_LOSS if get_loss else 0)
+                 | (_lib.C_RETURN_PATH if return_path else 0)
+                 | (_lib.C_SAVE_BWD if save_bwd else 0))
+        need = ctypes.c_size_t(0)
+        _lib.check(L.njode_workspace_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
+                                           ctypes.byref(need)))
+        call = _Call()
+        call.dims, call.batch, call.sched, call.flags = dims, cb, cs, flags
+        call.weight, call.p_drop = float(self.weight), float(self.dropout_rate)
+        # a fresh dropout stream per training forward, reproducible from `seed`
+        call.seed = (self.seed * 0x9E3779B97F4A7C15 + self._step_counter) & 0xFFFFFFFFFFFFFFFF
+        if self.training:
+            self._step_counter += 1
+        call.ws_slot = self._acquire_ws(need.value, dev)
+        call.ws = call.ws_slot[0]
+        call.keep = keep + [pinned]
+        return call, sched, slot_i, B
+
+    def _run_forward(self, call, hT, loss, path_h, path_y, slot_i):
+        L = _lib.lib()
+        stream = torch.cuda.current_stream()
+        rc = L.njode_forward_f32(
+            ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),
+            ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
+            hT.data_ptr(), loss.data_ptr() if loss is not None else None,
+            path_h.data_ptr() if path_h is not None else None,
+            path_y.data_ptr() if path_y is not None else None,
+            call.ws.data_ptr(), call.ws.numel(), stream.cuda_stream)
+        self._ring.release_after(slot_i, stream)
+        _lib.check(rc)
+
+    def _run_backward(self, call, grad_loss, grad_flat):
+        L = _lib.lib()
+        stream = torch.cuda.current_stream()
+        _lib.check(L.njode_backward_f32(
+            ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),
+            ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
+            grad_loss.data_ptr(), grad_flat.data_ptr(), call.ws.data_ptr(), call.ws.numel(),
+            stream.cuda_stream))
+
+    # -- forward -------------------------------------------------------------------------
+    def forward(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
+                return_path=False, get_loss=True, until_T=False, M=None):
+        """Same contract as the reference's ``NJODE.forward`` (``models.py:379-518``):
+        returns ``(hT, loss)`` or ``(hT, loss, path_t, path_h, path_y)``; ``loss`` is
+        the Python int 0 when ``get_loss=False``."""
+        want_grad = (torch.is_grad_enabled() and get_loss
+                     and any(p.requires_grad for p in self.parameters()))
+        call, sched, slot_i, B = self._make_call(
+            times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, return_path,
+            get_loss, until_T, M, save_bwd=want_grad)
+        dev = start_X.device
+        hT = torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev) if get_loss else None
+        path_h = path_y = None
+        if return_path:
+            path_h = torch.empty(sched.n_rows, B, self.hidden_size, dtype=torch.float32,
+                                 device=dev)
+            path_y = torch.empty(sched.n_rows, B, self.output_size, dtype=torch.float32,
+                                 device=dev)
+        try:
+            self._run_forward(call, hT, loss, path_h, path_y, slot_i)
+        except Exception:
+            self._release_ws(call)
+            raise
+        if want_grad:
+            self._ensure_flat()
+            loss_out = _NJODEFunction.apply(self, call, loss, *self._flat_params).reshape(())
+        else:
+            self._release_ws(call)
+            loss_out = loss.reshape(()) if get_loss else 0
+        if get_loss and not self.device_outputs:
+            loss_out = loss_out.cpu()       # reference harness calls .numpy() on it
+        if return_path:
+            return hT, loss_out, sched.path_t.copy(), path_h, path_y
+        return hT, loss_out
+
+    # -- fused training step (no autograd graph) ------------------------------------------
+    def loss_and_grad(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
+                      M=None):
+        """Forward + exact gradient in two library calls, no autograd bookkeeping:
+        returns the device loss tensor and fills ``flat_grad()`` (whose slices are
+        the parameters' ``.grad``).  Used by the build's harness and bench."""
+        grad = self.flat_grad()
+        call, sched, slot_i, B = self._make_call(
+            times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
+            M, save_bwd=True)
+        dev = start_X.device
+        hT = torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        try:
+            self._run_forward(call, hT, loss, None, None, slot_i)
+            if self._ones is None or self._ones.device != dev:
+                self._ones = torch.ones(1, dtype=torch.float32, device=dev)
+            self._run_backward(call, self._ones, grad)
+        finally:
+            self._release_ws(call)
+        return hT, loss.reshape(())
+
+    # -- evaluation helpers ---------------------------------------------------------------
+    def evaluate(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
+                 stockmodel, cond_exp_fun_kwargs=None,
+                 diff_fun=lambda x, y: np.mean((x - y) ** 2), return_paths=False, M=None):
+        """Distance of the predicted path to the true conditional expectation
+        (reference ``models.py:521-562``)."""
+        self.eval()
+        _, _, path_t, path_h, path_y = self.forward(
+            times, time_ptr, X, obs_idx, delta_t, T, start_X, None, return_path=True,
+            get_loss=False, until_T=True, M=M)
+        _, true_path_t, true_path_y = stockmodel.compute_cond_exp(
+            times, time_ptr, X.detach().cpu().numpy(), obs_idx.detach().cpu().numpy(),
+            delta_t, T, start_X.detach().cpu().numpy(), n_obs_ot.detach().cpu().numpy(),
+            return_path=True, get_loss=False)
+        eval_loss = diff_fun(path_y.detach().cpu().numpy(), true_path_y)
+        if return_paths:
+            return eval_loss, path_t, true_path_t, path_y, true_path_y
+        return eval_loss
+
+    def get_pred(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, M=None):
+        """Predicted path (reference ``models.py:564-584``)."""
+        self.eval()
+        _, _, path_t, path_h, path_y = self.forward(
+            times, time_ptr, X, obs_idx, delta_t, T, start_X, None, return_path=True,
+            get_loss=False, until_T=True, M=M)
+        if not self.device_outputs:
+            path_y = path_y.cpu()           # reference harness calls .numpy() on it
+        return {'pred': path_y, 'pred_t': path_t}
+
+
+class FusedAdam:
+    """``torch.optim.Adam(lr, betas, eps, weight_decay)`` on the model's flat
+    parameter vector in one kernel (``njode_adam_step_f32``), optionally preceded by
+    the data-parallel gradient all-reduce (one RCCL all-reduce of P floats)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 process_group=None, distributed=False):
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        flat = model.flat_parameters()
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.distributed = distributed
+        self.group = process_group
+
+    def zero_grad(self):
+        pass  # loss_and_grad overwrites the flat gradient
+
+    def step(self):
+        m = self.model
+        flat, grad = m.flat_parameters(), m.flat_grad()
+        if self.exp_avg.device != flat.device:
+            self.exp_avg = self.exp_avg.to(flat.device)
+            self.exp_avg_sq = self.exp_avg_sq.to(flat.device)
+        if self.distributed:
+            torch.distributed.all_reduce(grad, group=self.group)
+        self.step_count += 1
+        _lib.check(_lib.lib().njode_adam_step_f32(
+            flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+            self.exp_avg_sq.data_ptr(), flat.numel(), self.lr, self.betas[0], self.betas[1],
+            self.eps, self.weight_decay, self.step_count, 1.0,
+            torch.cuda.current_stream().cuda_stream))
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg.clone(),
+                'exp_avg_sq': self.exp_avg_sq.clone(), 'lr': self.lr, 'betas': self.betas,
+                'eps': self.eps, 'weight_decay': self.weight_decay}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])

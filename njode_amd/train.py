@@ -1,0 +1,158 @@
+"""
+Training / evaluation loop for the HIP-backed NJ-ODE model.
+
+Reproduces the compute semantics of the reference harness ``NJODE/train.py`` for the
+hot path -- nothing of its experiment management (model-id registry, plots, Telegram):
+
+* data split ``train_test_split(arange(N), test_size, random_state=seed)``
+  (``train.py:232-235``) -- implemented with numpy's RandomState-compatible
+  permutation of sklearn's ShuffleSplit (same indices, asserted in the tests when
+  sklearn is importable);
+* per optimizer step (``train.py:491-523``): recount ``n_obs_ot`` from ``obs_idx``,
+  ``model(...)`` in train mode, backward, ``Adam(lr, weight_decay=5e-4)``;
+* per epoch (``train.py:527-574, 623-624``): eval loss on the whole validation set as
+  one batch in eval mode, ``model.epoch += 1``, ``model.weight_decay_step()``;
+  ``train_loss`` logged = loss of the last batch of the epoch;
+* ``compute_optimal_eval_loss`` (``train.py:648-670``) from the analytic conditional
+  expectation; optional ``evaluate`` mean-square distance (``train.py:562-566``).
+
+The fused step (``NJODE.loss_and_grad`` + ``FusedAdam``) is used by default; pass
+``fused=False`` to drive the model exactly like the reference does
+(``loss.backward()`` + ``torch.optim.Adam``).  With torch.distributed initialised the
+loop is data parallel (see ``parallel.py``).
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import data_utils, models, parallel, stock_model
+
+METR_COLUMNS = ['epoch', 'train_time', 'eval_time', 'train_loss', 'eval_loss',
+                'optimal_eval_loss']
+
+
+def split_indices(n, test_size=0.2, seed=398):
+    """sklearn.model_selection.train_test_split(np.arange(n), test_size, random_state)
+    without sklearn: ShuffleSplit draws one RandomState(seed).permutation(n); the first
+    n_test entries are the test set, the next n_train the training set."""
+    n_test = int(np.ceil(test_size * n))
+    n_train = n - n_test
+    perm = np.random.RandomState(seed).permutation(n)
+    return perm[n_test:n_test + n_train], perm[:n_test]
+
+
+def compute_optimal_eval_loss(batch, stockmodel, delta_t, T, weight=0.5):
+    return stockmodel.get_optimal_loss(
+        batch['times'], batch['time_ptr'], batch['X'].numpy(), batch['obs_idx'].numpy(),
+        delta_t, T, batch['start_X'].numpy(), batch['n_obs_ot'].numpy(), weight=weight)
+
+
+def _device_batch(b, device):
+    return {'times': b['times'], 'time_ptr': b['time_ptr'], 'X': b['X'].to(device),
+            'start_X': b['start_X'].to(device),
+            'obs_idx': b['obs_idx'].to(device, torch.int32),
+            'n_obs_ot': data_utils.recount_observations(
+                b['obs_idx'], b['start_X'].shape[0]).to(device, torch.int32)}
+
+
+def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3,
+          hidden_size=10, bias=True, dropout_rate=0.1,
+          ode_nn=((50, 'tanh'), (50, 'tanh')), readout_nn=((50, 'tanh'), (50, 'tanh')),
+          enc_nn=((50, 'tanh'), (50, 'tanh')), use_rnn=False, solver='euler', weight=0.5,
+          weight_decay=1., test_size=0.2, seed=398, device='cuda', fused=True,
+          evaluate=False, shuffle_seed=0, log=print, max_steps_per_epoch=None,
+          **options):
+    """Train on an in-memory dataset ``(stock_paths, observed_dates, nb_obs)`` with
+    ``metadata`` as returned by ``data_utils.create_dataset``.  Returns
+    ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch."""
+    stock_paths, observed_dates, nb_obs = dataset_arrays
+    delta_t, T = metadata['dt'], metadata['maturity']
+    input_size = output_size = metadata['dimension']
+    world, rank, local_rank = parallel.init_distributed() if torch.distributed.is_initialized() \
+        else (1, 0, 0)
+    functions = options.get('func_appl_X')
+    funcs = tuple(f for f in (data_utils._get_func(n) for n in (functions or [])) if f)
+    mult = len(funcs) + 1
+
+    train_idx, val_idx = split_indices(len(nb_obs), test_size, seed)
+    model_opts = dict(options)
+    model_opts['device_outputs'] = True
+    torch.manual_seed(0)
+    model = models.NJODE(input_size * mult, hidden_size, output_size * mult, ode_nn,
+                         readout_nn, enc_nn, use_rnn, bias=bias, dropout_rate=dropout_rate,
+                         solver=solver, weight=weight, weight_decay=weight_decay,
+                         options=model_opts).to(device)
+    parallel.broadcast_parameters_(model.flat_parameters())
+    if fused:
+        optimizer = models.FusedAdam(model, lr=learning_rate, weight_decay=0.0005,
+                                     distributed=world > 1)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, weight_decay=0.0005)
+
+    val = data_utils.collate_arrays(stock_paths[val_idx], observed_dates[val_idx],
+                                    nb_obs[val_idx], delta_t, funcs)
+    stockmodel = stock_model.STOCK_MODELS[metadata['model_name']](**metadata)
+    opt_eval_loss = compute_optimal_eval_loss(val, stockmodel, delta_t, T) if mult == 1 \
+        else float('nan')
+    val_d = _device_batch(val, device)
+    val_d['n_obs_ot'] = val['n_obs_ot'].to(device, torch.int32)   # eval uses the dataset's count
+
+    metrics = []
+    while model.epoch <= epochs:
+        t0 = time.time()
+        model.train()
+        order = train_idx[parallel.epoch_permutation(len(train_idx), model.epoch, shuffle_seed)]
+        n_steps = (len(order) + batch_size - 1) // batch_size
+        if max_steps_per_epoch:
+            n_steps = min(n_steps, max_steps_per_epoch)
+        loss = None
+        for s in range(n_steps):
+            idx = order[s * batch_size:(s + 1) * batch_size]
+            lo, hi = parallel.shard_range(len(idx), world, rank)
+            parallel.configure_model(model, len(idx), lo)
+            mine = idx[lo:hi]
+            b = data_utils.collate_arrays(stock_paths[mine], observed_dates[mine], nb_obs[mine],
+                                          delta_t, funcs)
+            d = _device_batch(b, device)
+            args = (d['times'], d['time_ptr'], d['X'], d['obs_idx'], delta_t, T, d['start_X'],
+                    d['n_obs_ot'])
+            optimizer.zero_grad()
+            if fused:
+                _, loss = model.loss_and_grad(*args)
+            else:
+                _, loss = model(*args, return_path=False, get_loss=True)
+                loss.backward()
+                if world > 1:
+                    for p in model.parameters():
+                        parallel.allreduce_flat_(p.grad)
+            optimizer.step()
+        torch.cuda.synchronize()
+        train_time = time.time() - t0
+
+        t0 = time.time()
+        parallel.configure_model(model, val['start_X'].shape[0], 0)
+        model.dp_global_batch = None
+        with torch.no_grad():
+            model.eval()
+            _, c_loss = model(val_d['times'], val_d['time_ptr'], val_d['X'], val_d['obs_idx'],
+                              delta_t, T, val_d['start_X'], val_d['n_obs_ot'],
+                              return_path=False, get_loss=True)
+            loss_val = float(c_loss)
+            row_extra = []
+            if evaluate:
+                row_extra = [model.evaluate(
+                    val_d['times'], val_d['time_ptr'], val_d['X'], val['obs_idx'], delta_t, T,
+                    val_d['start_X'], val['n_obs_ot'], stockmodel)]
+        eval_time = time.time() - t0
+        train_loss = float(parallel.allreduce_flat_(loss.detach().reshape(1).clone())) \
+            if loss is not None else float('nan')
+        if rank == 0:
+            log("epoch {}, weight={:.5f}, train-loss={:.5f}, optimal-eval-loss={:.5f}, "
+                "eval-loss={:.5f}, ".format(model.epoch, model.weight, train_loss,
+                                            opt_eval_loss, loss_val))
+        metrics.append([model.epoch, train_time, eval_time, train_loss, loss_val,
+                        opt_eval_loss] + row_extra)
+        model.epoch += 1
+        model.weight_decay_step()
+    return model, metrics

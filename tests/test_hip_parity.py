@@ -1,0 +1,241 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C ABI of libnjode_hip.so, against (1) golden vectors produced by the reference itself
+and (2) the CPU oracle on seeded inputs.  Tolerances: hip_util.py."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, all_model_cases
+from hip_util import (ATOL, GRAD_REL_L2, LOSS_RTOL, RTOL, bs_batch, demo_cfg, grads_by_name,
+                      hip_forward, hip_model, oracle_forward, rel_l2, to_dev)
+from njode_amd import _lib, data_utils, models, stock_model
+
+pytestmark = pytest.mark.gpu
+
+HIP_CASES = [n for n in all_model_cases() if n != 'g6_use_rnn']
+SEG_GRAD_CASES = [n for n in HIP_CASES if not n.startswith(('g1_', 'g5_'))]
+
+
+def test_native_library_is_loaded():
+    assert torch.cuda.is_available()
+    assert _lib.build_info().startswith('gfx950;')
+
+
+@pytest.mark.parametrize('name', HIP_CASES)
+def test_eval_path_matches_reference(name):
+    """lockstep plan: full prediction path incl. the until_T tail vs the reference."""
+    g = Golden(name)
+    if 'path_y' not in g:
+        pytest.skip('no eval outputs in this golden file')
+    m = hip_model(g.cfg, g.state_dict()).eval()
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = hip_forward(
+            m, g.batch(), g.delta_t, g.T, return_path=True, get_loss=True, until_T=True)
+    assert np.array_equal(path_t, g['path_t'])
+    np.testing.assert_allclose(path_y.cpu().numpy(), g['path_y'], atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(hT.cpu().numpy(), g['hT'], atol=ATOL, rtol=RTOL)
+    if 'path_h' in g:
+        np.testing.assert_allclose(path_h.cpu().numpy(), g['path_h'], atol=ATOL, rtol=RTOL)
+    assert float(loss) == pytest.approx(float(g['loss']), rel=LOSS_RTOL)
+
+
+@pytest.mark.parametrize('name', [n for n in HIP_CASES if not n.startswith('g5_')])
+def test_training_style_forward_matches_reference(name):
+    """segment plan (no path, stop at the last observation): hT and loss."""
+    g = Golden(name)
+    m = hip_model(g.cfg, g.state_dict()).eval()
+    with torch.no_grad():
+        hT, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
+    if 'loss_lastobs' in g:
+        ref_h, ref_loss = g['hT_lastobs'], float(g['loss_lastobs'])
+    else:
+        (h_o, l_o), _ = oracle_forward(g.cfg, g.state_dict(), g.batch(), g.delta_t, g.T,
+                                       weight=g.cfg.get('weight'))
+        ref_h, ref_loss = h_o.detach().numpy(), float(l_o)
+    np.testing.assert_allclose(hT.cpu().numpy(), ref_h, atol=ATOL, rtol=RTOL)
+    assert float(loss) == pytest.approx(ref_loss, rel=LOSS_RTOL)
+
+
+@pytest.mark.parametrize('name', SEG_GRAD_CASES)
+def test_gradients_match_reference(name):
+    """loss.backward() through the autograd bridge == reference autograd gradients."""
+    g = Golden(name)
+    m = hip_model(g.cfg, g.state_dict()).train()      # dropout_rate = 0 in these cases
+    _, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g['train_loss']), rel=LOSS_RTOL)
+    got = grads_by_name(m)
+    for k, ref in g.group('grad').items():
+        assert rel_l2(got[k], ref) < GRAD_REL_L2, (k, rel_l2(got[k], ref))
+
+
+def test_default_outputs_follow_reference_harness_conventions():
+    """Without device_outputs the loss / prediction are CPU tensors (the reference
+    harness calls .numpy() on them) and backward still works."""
+    g = Golden('g2_bs_grads_B64')
+    m = hip_model(g.cfg, g.state_dict(), device_outputs=False).train()
+    _, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
+    assert loss.device.type == 'cpu' and loss.requires_grad
+    loss.backward()
+    assert loss.detach().numpy() == pytest.approx(float(g['train_loss']), rel=LOSS_RTOL)
+    assert rel_l2(grads_by_name(m)['ode_f.f.3.weight'], g['grad/ode_f.f.3.weight']) < GRAD_REL_L2
+    b = to_dev(g.batch())
+    pred = m.get_pred(b['times'], b['time_ptr'], b['X'], b['obs_idx'], g.delta_t, g.T,
+                      b['start_X'])
+    assert pred['pred'].device.type == 'cpu' and pred['pred'].numpy().shape[1] == 64
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_adam_steps_match_reference(fused):
+    """5 optimizer steps (train.py:492-523 semantics) with torch.optim.Adam on the
+    autograd path and with the fused flat path (loss_and_grad + njode_adam_step_f32)."""
+    g = Golden('g2_bs_grads_B64')
+    m = hip_model(g.cfg, g.state_dict()).train()
+    b = to_dev(g.batch())
+    n_obs_ot = data_utils.recount_observations(g.batch()['obs_idx'], 64).cuda()
+    args = (b['times'], b['time_ptr'], b['X'], b['obs_idx'], g.delta_t, g.T, b['start_X'],
+            n_obs_ot)
+    if fused:
+        opt = models.FusedAdam(m, lr=1e-3, weight_decay=0.0005)
+    else:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0005)
+    losses = []
+    for step in range(1, 6):
+        opt.zero_grad()
+        if fused:
+            _, loss = m.loss_and_grad(*args)
+        else:
+            _, loss = m(*args)
+            loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        if step in (1, 5):
+            sd = m.state_dict()
+            for k, ref in g.group('adam{}'.format(step)).items():
+                np.testing.assert_allclose(sd[k].cpu().numpy(), ref, atol=2e-5, rtol=1e-4,
+                                           err_msg='{} step {}'.format(k, step))
+    np.testing.assert_allclose(losses, g['adam_losses'], rtol=2e-4)
+
+
+@pytest.mark.parametrize('tag,name', [('BS', 'BlackScholes'), ('Heston', 'Heston'),
+                                      ('OU', 'OrnsteinUhlenbeck')])
+def test_shipped_checkpoint_known_answers(tag, name):
+    """BASELINE config 3: the reference's pre-trained weights on the N=200 seed-0
+    datasets: eval loss and mean-square distance to the analytic conditional
+    expectation within 1e-3 of the reference's values."""
+    g = Golden('g3_ckpt_' + tag)
+    b, meta = bs_batch(200, name=name)
+    m = hip_model(g.cfg, g.state_dict()).eval()
+    m.weight = float(g['ckpt_weight'])
+    d = to_dev(b)
+    with torch.no_grad():
+        _, loss = m(d['times'], d['time_ptr'], d['X'], d['obs_idx'], meta['dt'],
+                    meta['maturity'], d['start_X'], d['n_obs_ot'])
+    sm = stock_model.STOCK_MODELS[name](**meta)
+    msd = m.evaluate(d['times'], d['time_ptr'], d['X'], d['obs_idx'], meta['dt'],
+                     meta['maturity'], d['start_X'], d['n_obs_ot'], sm)
+    assert float(loss) == pytest.approx(float(g['eval_loss']), rel=LOSS_RTOL)
+    assert msd == pytest.approx(float(g['msd_cond_exp']), rel=1e-3)
+
+
+def test_larger_batch_loss_and_grads_vs_oracle():
+    """B = 1500 seeded Black-Scholes batch, random-init weights: both plans and the
+    gradient against the CPU oracle."""
+    torch.manual_seed(1)
+    cfg = demo_cfg()
+    b, meta = bs_batch(1500, seed=3)
+    m = hip_model(cfg).train()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    (h_o, l_o), params = oracle_forward(cfg, sd, b, meta['dt'], meta['maturity'], grads=True)
+    l_o.backward()
+    hT, loss = hip_forward(m, b, meta['dt'], meta['maturity'])
+    loss.backward()
+    assert float(loss) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+    np.testing.assert_allclose(hT.detach().cpu().numpy(), h_o.detach().numpy(), atol=ATOL,
+                               rtol=RTOL)
+    got = grads_by_name(m)
+    for k, p in params.items():
+        assert rel_l2(got[k], p.grad.numpy()) < GRAD_REL_L2, k
+    m.eval()
+    with torch.no_grad():   # lockstep plan on the same batch
+        hT2, loss2, _, _, path_y = hip_forward(m, b, meta['dt'], meta['maturity'],
+                                               return_path=True, get_loss=True)
+    assert float(loss2) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+    np.testing.assert_allclose(hT2.cpu().numpy(), h_o.detach().numpy(), atol=ATOL, rtol=RTOL)
+
+
+def test_masked_backward_fails_loudly():
+    g = Golden('g5_masked')
+    m = hip_model(g.cfg, g.state_dict()).train()
+    with pytest.raises(NotImplementedError, match='segment plan'):
+        hip_forward(m, g.batch(), g.delta_t, g.T)
+
+
+def test_use_rnn_fails_loudly():
+    g = Golden('g6_use_rnn')
+    m = hip_model(g.cfg, g.state_dict())
+    with pytest.raises(NotImplementedError, match='use_rnn'):
+        hip_forward(m, g.batch(), g.delta_t, g.T)
+
+
+def test_unsupported_shape_fails_loudly():
+    nn = ((33, 'tanh'), (33, 'tanh'))
+    m = models.NJODE(1, 10, 1, nn, nn, nn, use_rnn=False, options={}).cuda()
+    b, meta = bs_batch(8)
+    with pytest.raises(NotImplementedError, match='no gfx950 specialisation'):
+        hip_forward(m, b, meta['dt'], meta['maturity'])
+
+
+def test_edge_cases_no_observations_and_single_path():
+    cfg = demo_cfg()
+    m = hip_model(cfg).eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    b, meta = bs_batch(6, seed=5)
+    # (a) a batch in which nobody is observed: loss 0, hT = encoder(start_X)
+    empty = dict(b, times=np.zeros(0), time_ptr=np.zeros(1, dtype=np.int64),
+                 X=torch.zeros(0, 1), obs_idx=torch.zeros(0, dtype=torch.long),
+                 n_obs_ot=torch.zeros(6, dtype=torch.long))
+    with torch.no_grad():
+        hT, loss = hip_forward(m, empty, meta['dt'], meta['maturity'])
+        (h_o, _), _ = oracle_forward(cfg, sd, empty, meta['dt'], meta['maturity'],
+                                     get_loss=False)
+    assert float(loss) == 0.0
+    np.testing.assert_allclose(hT.cpu().numpy(), h_o.numpy(), atol=ATOL, rtol=RTOL)
+    # (b) B = 1
+    b1, meta1 = bs_batch(1, seed=11, obs_perc=0.3)
+    with torch.no_grad():
+        hT, loss, _, _, path_y = hip_forward(m, b1, meta1['dt'], meta1['maturity'],
+                                             return_path=True, until_T=True)
+        (h_o, l_o, _, _, y_o), _ = oracle_forward(cfg, sd, b1, meta1['dt'], meta1['maturity'],
+                                                  return_path=True, until_T=True)
+    np.testing.assert_allclose(path_y.cpu().numpy(), y_o.numpy(), atol=ATOL, rtol=RTOL)
+    assert float(loss) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+
+
+def test_c_abi_error_codes():
+    L = _lib.lib()
+    d = _lib.NjodeDims(1, 10, 1, 2, 50, 0, _lib.F_RESIDUAL)
+    z = torch.zeros(16, device='cuda')
+    rc = L.njode_forward_f32(ctypes.byref(d), None, None, None, 0, 0.5, 0.0, 0, None, None,
+                             None, None, None, 0, None)
+    assert rc == _lib.E_BADARG and b'null' in L.njode_last_error()
+    rc = L.njode_adam_step_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 16,
+                               1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 1.0, None)
+    assert rc == _lib.E_BADARG
+    # too small a workspace
+    g = Golden('g1_bs_eval_B7')
+    m = hip_model(g.cfg, g.state_dict()).eval()
+    b = to_dev(g.batch())
+    call, sched, slot, B = m._make_call(b['times'], b['time_ptr'], b['X'], b['obs_idx'],
+                                        g.delta_t, g.T, b['start_X'], b['n_obs_ot'], False,
+                                        True, False, None, save_bwd=False)
+    hT = torch.empty(B, 10, device='cuda')
+    loss = torch.zeros(1, device='cuda')
+    rc = L.njode_forward_f32(ctypes.byref(call.dims), m._flat.data_ptr(),
+                             ctypes.byref(call.batch), ctypes.byref(call.sched), call.flags,
+                             0.5, 0.0, 0, hT.data_ptr(), loss.data_ptr(), None, None,
+                             call.ws.data_ptr(), 1024, None)
+    assert rc == _lib.E_WORKSPACE and b'workspace too small' in L.njode_last_error()
+    m._release_ws(call)

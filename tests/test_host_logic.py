@@ -1,0 +1,174 @@
+"""CPU tests of the host side of the HIP path: the float64 step schedule, the flat
+parameter layout, the operator surface, and that libnjode_hip.so loads and exports
+every symbol include/njode_hip.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, all_model_cases
+from njode_amd import _lib, models
+from njode_amd.schedule import Schedule, ScheduleCache
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('name', [n for n in all_model_cases() if n != 'g2_bs_grads_B64'])
+def test_schedule_reproduces_reference_clock(name):
+    """path_t of the reference (float64 clock incl. partial steps, t=0 jump, empty
+    slices, until_T tail) is reproduced exactly; fp32 arrays are consistent with it."""
+    g = Golden(name)
+    s = Schedule(g['times'], g.delta_t, g.T, until_T=True)
+    assert np.array_equal(s.path_t, g['path_t'])
+    assert s.n_rows == len(g['path_t'])
+    assert s.n_times == len(g['times'])
+    assert np.all(np.diff(s.k_jump) >= 0)
+    assert np.array_equal(s.time_f32, g['times'].astype(np.float32))
+    # rows: jump i sits right after the row of Euler step k_jump[i]-1
+    assert np.array_equal(s.path_t[s.row_of_jump], g['times'])
+    # steps sum to the clock
+    assert abs(float(s.step_dt.astype(np.float64).sum()) - s.path_t[-1]) < 1e-4
+
+
+def test_schedule_without_tail_and_offgrid():
+    g = Golden('g6_offgrid_dt')
+    s = Schedule(g['times'], g.delta_t, g.T, until_T=False)
+    assert s.n_steps == s.k_jump[-1]                       # no tail
+    s2 = Schedule(g['times'], g.delta_t, g.T, until_T=True)
+    assert s2.n_steps > s.n_steps                          # T=1.05 tail
+    # dt 0.004 on a 0.01 grid: 2 full + 1 partial step per interval
+    d = s.step_dt[:3].astype(np.float64)
+    assert d[0] == pytest.approx(0.004) and d[2] == pytest.approx(0.002, rel=1e-5)
+
+
+def test_schedule_grid_data_rounds_to_one_dt():
+    g = Golden('g1_bs_eval_B200')
+    s = Schedule(g['times'], g.delta_t, g.T, until_T=False)
+    assert s.n_steps == 100 and len(set(s.step_dt.tolist())) == 1
+
+
+def test_schedule_cache_and_packing():
+    g = Golden('g1_bs_eval_B7')
+    c = ScheduleCache(capacity=2)
+    a = c.get(g['times'], g.delta_t, g.T, True)
+    assert c.get(g['times'].copy(), g.delta_t, g.T, True) is a
+    assert c.get(g['times'], g.delta_t, g.T, False) is not a
+    buf = np.zeros(a.packed_nbytes() // 4 + 8, dtype=np.int32)
+    K, nt = a.pack_into(buf, g['time_ptr'].astype(np.int32))
+    f = buf.view(np.float32)
+    assert np.array_equal(f[:K], a.step_dt) and np.array_equal(f[K:2 * K], a.step_t)
+    assert np.array_equal(buf[2 * K:2 * K + nt], a.k_jump)
+    assert np.array_equal(buf[2 * K + 2 * nt:2 * K + 3 * nt + 1], g['time_ptr'])
+
+
+def _demo_model(**opts):
+    nn = ((50, 'tanh'), (50, 'tanh'))
+    return models.NJODE(1, 10, 1, nn, nn, nn, use_rnn=False, bias=True, dropout_rate=0.1,
+                        options=opts, epochs=3, batch_size=100, dataset='BlackScholes')
+
+
+def test_operator_surface_and_state_dict_keys():
+    g = Golden('g1_bs_eval_B7')
+    m = _demo_model()
+    assert list(m.state_dict().keys()) == list(g.state_dict().keys())
+    assert sum(p.numel() for p in m.parameters()) == 10071
+    assert m.epoch == 1 and m.weight == 0.5
+    m.load_state_dict(g.state_dict())
+    for name in ('NJODE', 'ODEFunc', 'FFNN', 'GRUCell', 'get_ffnn', 'compute_loss',
+                 'compute_loss_2', 'LOSS_FUN_DICT', 'nonlinears', 'init_weights',
+                 'save_checkpoint', 'get_ckpt_model'):
+        assert hasattr(models, name)
+    m.weight, m.weight_decay = 0.9, 0.5
+    assert m.weight_decay_step() == pytest.approx(0.7)
+    with pytest.raises(RuntimeError):
+        m.encoder_map(torch.zeros(1, 1))       # parameter container only: no eager path
+
+
+def test_flat_parameter_views_follow_state_dict_and_to():
+    g = Golden('g1_bs_eval_B7')
+    m = _demo_model()
+    flat = m.flat_parameters()
+    assert flat.numel() == 10071
+    m.load_state_dict(g.state_dict())          # in-place copy keeps the views
+    assert m.flat_parameters() is flat
+    sd = g.state_dict()
+    off = 0
+    for k in sd:                               # flat layout == state_dict order
+        n = sd[k].numel()
+        assert torch.equal(flat[off:off + n], sd[k].reshape(-1)), k
+        off += n
+    w = m.ode_f.f[0].weight
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert torch.equal(m.flat_parameters()[:w.numel()], w.reshape(-1))
+    m.to(torch.float32)                        # no-op keeps views
+    assert m.flat_parameters() is flat
+
+
+def test_bias_free_model_keeps_zero_bias_slots():
+    nn = ((50, 'tanh'), (50, 'tanh'))
+    m = models.NJODE(1, 10, 1, nn, nn, nn, use_rnn=False, bias=False, options={})
+    assert sum(p.numel() for p in m.parameters()) == 10071 - (50 + 50 + 10) * 2 - (50 + 50 + 1)
+    flat = m.flat_parameters()
+    assert flat.numel() == 10071
+    assert float(flat[650:700].abs().sum()) == 0.0      # ode_f.f.0 bias slot
+
+
+def test_residual_size_errors_match_reference():
+    nn = ((50, 'tanh'), (50, 'tanh'))
+    with pytest.raises(ValueError, match='output_size needs to be multiple of input_size'):
+        models.NJODE(41, 50, 41, nn, nn, nn, use_rnn=False, options={'masked': True})
+    models.NJODE(41, 50, 41, nn, nn, nn, use_rnn=False,
+                 options={'masked': True, 'residual_enc_dec': False})
+
+
+def test_cpu_device_fails_loudly():
+    g = Golden('g1_bs_eval_B7')
+    m = _demo_model()
+    b = g.batch()
+    with pytest.raises((RuntimeError, ImportError)):
+        m(b['times'], b['time_ptr'], b['X'], b['obs_idx'], g.delta_t, g.T, b['start_X'],
+          b['n_obs_ot'])
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    m = _demo_model()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0005)
+    m.weight = 0.7
+    models.save_checkpoint(m, opt, str(tmp_path), epoch=4)
+    ck = torch.load(str(tmp_path / 'checkpt.tar'), weights_only=False)
+    assert set(ck) == {'epoch', 'weight', 'model_state_dict', 'optimizer_state_dict'}
+    m2 = _demo_model()
+    models.get_ckpt_model(str(tmp_path), m2, torch.optim.Adam(m2.parameters()), 'cpu')
+    assert m2.epoch == 4 and m2.weight == 0.7
+    assert torch.equal(m2.flat_parameters(), m.flat_parameters())
+
+
+def test_library_loads_and_exports_declared_symbols():
+    """Every function declared in include/njode_hip.h is exported by the built
+    library (built by __graft_entry__.build(); no GPU needed to load it)."""
+    header = open(os.path.join(REPO, 'include', 'njode_hip.h')).read()
+    declared = set(re.findall(r'\b(njode_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_lib.EXPORTS)
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libnjode_hip.so not built in this checkout (run __graft_entry__.build())')
+    L = _lib.lib()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    info = _lib.build_info()
+    assert info.startswith('gfx950;') and 'd1.h10.o1.nh2.w50' in info
+    d = _lib.NjodeDims(1, 10, 1, 2, 50, 0, _lib.F_RESIDUAL)
+    assert L.njode_supported(ctypes.byref(d)) == 1
+    assert L.njode_param_count(ctypes.byref(d)) == 10071
+    d2 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, 0)
+    assert L.njode_supported(ctypes.byref(d2)) == 0
+    need = ctypes.c_size_t(0)
+    assert L.njode_workspace_bytes(ctypes.byref(d), 100, 1000, 100, 100,
+                                   _lib.C_GET_LOSS | _lib.C_SAVE_BWD, ctypes.byref(need)) == 0
+    assert need.value > 100 * 100 * 10 * 4
+    assert L.njode_workspace_bytes(ctypes.byref(d2), 100, 1000, 100, 100, 0,
+                                   ctypes.byref(need)) == _lib.E_UNSUPPORTED
+    assert b'compiled' in L.njode_last_error()
