@@ -97,7 +97,7 @@ def build(force=False, jobs=None, verbose=True):
                     '-DNJ_H={}'.format(h), '-DNJ_DO={}'.format(do), '-DNJ_NH={}'.format(nh),
                     '-DNJ_W={}'.format(max(w, 1)), '-DNJ_ACT={}'.format(act),
                     '-DNJ_MASKED={}'.format(masked), '-DNJ_CURT={}'.format(curt),
-                    '-DNJ_RES={}'.format(res)]
+                    '-DNJ_RES={}'.format(res), '-DNJ_ACC_TANH={}'.format(masked)]
             cmd = common + defs + [os.path.join(CSRC, 'njode_cfg.hip'), '-o', obj]
             tasks.append((obj, cmd, _digest(kernel_deps, ' '.join(cmd))))
     api_obj = os.path.join(OBJ, 'api.o')

@@ -87,24 +87,16 @@ hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, hipStre
 #endif
 
 #if NJ_PART == 2
-template <bool DROP, bool PATH, bool LOSS> static hipError_t lock_t(const KArgs& a, hipStream_t st) {
+template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, hipStream_t st) {
   ProfScope ps("k_paths_fwd", st);
-  k_paths_fwd<C, DROP, PATH, LOSS><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+  a.want_path = path ? 1 : 0;
+  a.want_loss = loss ? 1 : 0;
+  k_paths_fwd<C, DROP><<<cdiv(a.B, 64), 64, 0, st>>>(a);
   return hipGetLastError();
 }
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
                                              hipStream_t st) {
-  const int sel = (drop ? 4 : 0) | (path ? 2 : 0) | (loss ? 1 : 0);
-  switch (sel) {
-    case 0: return lock_t<false, false, false>(a, st);
-    case 1: return lock_t<false, false, true>(a, st);
-    case 2: return lock_t<false, true, false>(a, st);
-    case 3: return lock_t<false, true, true>(a, st);
-    case 4: return lock_t<true, false, false>(a, st);
-    case 5: return lock_t<true, false, true>(a, st);
-    case 6: return lock_t<true, true, false>(a, st);
-    default: return lock_t<true, true, true>(a, st);
-  }
+  return drop ? lock_t<true>(a, path, loss, st) : lock_t<false>(a, path, loss, st);
 }
 #endif
 

@@ -33,9 +33,13 @@ constexpr int ACT_RELU = 1;
 // Re-materialise a uniform pointer so the compiler cannot hoist the (loop
 // invariant) weight loads out of a time loop and spill thousands of SGPRs.
 NJ_DEV cfp launder(cfp p) {
-  unsigned long long a = (unsigned long long)p;
-  asm volatile("" : "+s"(a));
-  return (cfp)a;
+  const unsigned long long v = (unsigned long long)p;
+  // readfirstlane: the pointer is uniform by construction, but after loops with
+  // lane-dependent bodies the compiler may hold it in a VGPR ("+s" then fails)
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return (cfp)(((unsigned long long)hi << 32) | lo);
 }
 NJ_DEV cfp as_cfp(const float* p) { return (cfp)(unsigned long long)p; }
 
@@ -48,11 +52,29 @@ template <int N> NJ_DEV void pin(float (&v)[N]) {
 }
 
 // ---- activations -------------------------------------------------------------
-// tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1): v_exp_f32 + v_rcp_f32, abs. error
-// ~1e-7, saturates cleanly (exp -> inf gives 1, exp -> 0 gives -1).
+// tanh(x) = 1 - 2 / (2^(2 log2(e) x) + 1): v_exp_f32 + v_rcp_f32; saturates cleanly
+// (exp -> inf gives 1, exp -> 0 gives -1).  Its ABSOLUTE error is ~1e-7 everywhere
+// (cancellation against 1 for small |x|), fine for the unmasked path.  Masked models
+// feed their own predictions back as inputs (self-imputation, models.py:465-467),
+// which amplifies rounding differences step after step, so those translation units are
+// built with NJ_ACC_TANH=1: |x| < 0.3 uses the odd Taylor polynomial to x^11
+// (truncation < 6e-10), keeping the error at a few ulp of the result.
+#ifndef NJ_ACC_TANH
+#define NJ_ACC_TANH 0
+#endif
 NJ_DEV float tanh_f(float x) {
-  float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+#if NJ_ACC_TANH
+  const float x2 = x * x;
+  float p = fmaf(x2, -8.8632355299021965e-3f, 2.1869488536155203e-2f);
+  p = fmaf(x2, p, -5.3968253968253971e-2f);
+  p = fmaf(x2, p, 1.3333333333333333e-1f);
+  p = fmaf(x2, p, -3.3333333333333331e-1f);
+  const float s = fmaf(x * x2, p, x);
+  t = fabsf(x) < 0.3f ? s : t;
+#endif
+  return t;
 }
 template <int ACT> NJ_DEV float act_f(float z) {
   if constexpr (ACT == ACT_TANH) return tanh_f(z);

@@ -85,6 +85,7 @@ struct KArgs {
   // options
   float weight;
   int loss_easy;
+  int want_path, want_loss;  // lockstep plan: return_path / get_loss (wave-uniform)
   DropCtx dc;
   float keep;
 };
@@ -500,8 +501,9 @@ __global__ void __launch_bounds__(64, 2) k_encode_rows_bwd(KArgs a) {
 // =====================================================================================
 // Lockstep plan: one lane per path over the shared grid (all modes, forward only)
 // =====================================================================================
-template <class C, bool DROP, bool PATH, bool LOSS>
+template <class C, bool DROP>
 __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
+  const bool PATH = a.want_path != 0, LOSS = a.want_loss != 0;  // uniform branches
   const int b0 = blockIdx.x * 64 + threadIdx.x;
   const bool valid = b0 < a.B;
   const int b = valid ? b0 : a.B - 1;
@@ -513,7 +515,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
   const int __attribute__((address_space(4)))* kjump =
       (const int __attribute__((address_space(4)))*)kj;
 
-  float xl[C::D], mask[C::D], h[C::H], y[C::DO];
+  float xl[C::D], mask[C::D], h[C::H], y[C::DO] = {};
   float ein[C::ENC_IN], a1[C::W], a2[C::W], th[C::H];
   load_vec(a.start_X + (size_t)b * C::D, xl);
 #pragma unroll
@@ -531,7 +533,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
   next_i = cur >= 0 ? next_i : 0x7fffffff;
   int row = 0;
   auto emit = [&](uint32_t tkey) {
-    if constexpr (PATH) {
+    if (PATH) {
       mk.draw(a, gid, tkey, NET_DEC_ROW);
       readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, y);
     }
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
   // `if` around the only use of a network's output makes the compiler sink the FMAs
   // into it and keep the whole network's scalar-loaded weights live (SGPR spills)
   auto write_row = [&]() {
-    if constexpr (PATH) {
+    if (PATH) {
       store_vec(valid ? a.path_h + ((size_t)row * a.B + b) * C::H : a.trash + threadIdx.x * C::H, h);
       store_vec(valid ? a.path_y + ((size_t)row * a.B + b) * C::DO
                       : a.trash + threadIdx.x * C::DO, y);
@@ -574,7 +576,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
           encode<C, DROP>(launder(Pe0), xin, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
           mk.draw(a, gid, (uint32_t)k, NET_DEC);
           readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, y);
-          if constexpr (LOSS) {
+          if (LOSS) {
             float dy[C::DO], dybj[C::DO];
             const float scale = a.inv_batch / (float)a.n_obs_ot[b];
             loss_acc += loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
@@ -609,9 +611,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
     }
   }
   store_vec(valid ? a.hT + (size_t)b * C::H : a.trash + threadIdx.x * C::H, h);
-  if constexpr (LOSS) {
-    if (valid) a.loss_terms[b] = loss_acc;
-  }
+  if (LOSS && valid) a.loss_terms[b] = loss_acc;
 }
 
 }  // namespace njode
