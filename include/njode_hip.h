@@ -122,7 +122,10 @@ int njode_workspace_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_o
  * observation times -> jump at observations -> readout -> paper loss
  * (models.py:71-126).
  *
- *   hT       [B, H]            hidden state at the end of the pass
+ *   hT       [B, H]            hidden state at the end of the pass (every path evolved
+ *                              to the last step of the schedule, as the reference
+ *                              does); may be NULL on the segment plan, which then
+ *                              skips the per-path tail evolve nobody reads
  *   loss     [1]               (written iff GET_LOSS) sum over this shard's rows
  *   path_h   [n_rows, B, H]    (iff RETURN_PATH) n_rows = 1 + n_steps + n_times
  *   path_y   [n_rows, B, d_out]

@@ -15,35 +15,43 @@ using C = Cfg<NJ_D, NJ_H, NJ_DO, NJ_NH, NJ_W, NJ_ACT, (NJ_MASKED != 0), (NJ_CURT
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool save, hipStream_t st);
-hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
+hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, bool wlds,
+                                            hipStream_t st);
+hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, bool wlds, hipStream_t st);
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
                                              hipStream_t st);
 
 #if NJ_PART == 0
-template <bool DROP> static hipError_t seg_forward_t(const KArgs& a, bool save, hipStream_t st) {
+template <bool DROP, bool WLDS>
+static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
   if constexpr (C::MASKED) {
     return hipErrorNotSupported;
   } else {
+    constexpr int NT = WLDS ? 256 : 64;
     {
       ProfScope ps("k_encode_rows", st);
       k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
     }
     {
       ProfScope ps("k_ode_fwd_items", st);
-      if (save) k_ode_fwd_items<C, DROP, true><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
-      else k_ode_fwd_items<C, DROP, false><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
+      k_ode_fwd_items<C, DROP, false, WLDS><<<cdiv(a.n_obs, NT), NT, 0, st>>>(a);
+    }
+    if (tails) {
+      ProfScope ps("k_ode_fwd_tails", st);
+      k_ode_fwd_items<C, DROP, true, WLDS><<<cdiv(a.B, NT), NT, 0, st>>>(a);
     }
     {
       ProfScope ps("k_jump_rows", st);
       k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
     }
-    k_gather_hT<C><<<cdiv(a.B, 256), 256, 0, st>>>(a);
     return hipGetLastError();
   }
 }
-hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool save, hipStream_t st) {
-  return drop ? seg_forward_t<true>(a, save, st) : seg_forward_t<false>(a, save, st);
+hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, bool wlds,
+                                            hipStream_t st) {
+  if (drop) return wlds ? seg_forward_t<true, true>(a, tails, st)
+                        : seg_forward_t<true, false>(a, tails, st);
+  return wlds ? seg_forward_t<false, true>(a, tails, st) : seg_forward_t<false, false>(a, tails, st);
 }
 
 const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
@@ -62,7 +70,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
 #endif
 
 #if NJ_PART == 1
-template <bool DROP> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
+template <bool DROP, bool WLDS> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
   if constexpr (C::MASKED) {
     return hipErrorNotSupported;
   } else {
@@ -72,7 +80,8 @@ template <bool DROP> static hipError_t seg_backward_t(const KArgs& a, hipStream_
     }
     {
       ProfScope ps("k_ode_bwd_items", st);
-      k_ode_bwd_items<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+      if constexpr (WLDS) k_ode_bwd_items<C, DROP, true><<<a.n_waves / 4, 256, 0, st>>>(a);
+      else k_ode_bwd_items<C, DROP, false><<<a.n_waves, 64, 0, st>>>(a);
     }
     {
       ProfScope ps("k_encode_rows_bwd", st);
@@ -81,8 +90,9 @@ template <bool DROP> static hipError_t seg_backward_t(const KArgs& a, hipStream_
     return hipGetLastError();
   }
 }
-hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
-  return drop ? seg_backward_t<true>(a, st) : seg_backward_t<false>(a, st);
+hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, bool wlds, hipStream_t st) {
+  if (drop) return wlds ? seg_backward_t<true, true>(a, st) : seg_backward_t<true, false>(a, st);
+  return wlds ? seg_backward_t<false, true>(a, st) : seg_backward_t<false, false>(a, st);
 }
 #endif
 

@@ -22,6 +22,7 @@ namespace njode {
 
 typedef const float __attribute__((address_space(4))) * cfp;  // scalar-load ptr
 typedef float __attribute__((address_space(3))) * lfp;        // LDS ptr
+typedef const float __attribute__((address_space(3))) * lcp;  // read-only LDS ptr (weights)
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef f4 __attribute__((address_space(3))) * lf4p;           // LDS ptr, 16 B
 
@@ -42,6 +43,13 @@ NJ_DEV cfp launder(cfp p) {
   return (cfp)(((unsigned long long)hi << 32) | lo);
 }
 NJ_DEV cfp as_cfp(const float* p) { return (cfp)(unsigned long long)p; }
+// same for a (32-bit) LDS address: keeps loop-invariant ds_reads of the weights from
+// being hoisted out of the time loop into hundreds of VGPRs
+NJ_DEV lcp launder(lcp p) {
+  unsigned v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p);
+  asm volatile("" : "+s"(v));
+  return (lcp)(unsigned long long)v;
+}
 
 // Pin values where they are computed.  Without it the compiler sinks a network's
 // FMAs into a later (divergent) block that holds their only use, while the scalar
@@ -136,8 +144,8 @@ template <int IN_, int OUT_, int NH_, int W_> struct NetL {
 };
 
 // out[j] = b[j] + sum_i W[j][i] in[i]
-template <int K, int N>
-NJ_DEV void dense(cfp Wp, cfp bp, const float (&in)[K], float (&out)[N]) {
+template <int K, int N, class WP>
+NJ_DEV void dense(WP Wp, WP bp, const float (&in)[K], float (&out)[N]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     float acc = bp[j];
@@ -149,8 +157,8 @@ NJ_DEV void dense(cfp Wp, cfp bp, const float (&in)[K], float (&out)[N]) {
 
 // Transposed product from the transposed copy WT[K][N]:
 //   g_i = sum_j WT[i][j] dout[j];   io[i] = f(i, g_i, io[i])   (in place)
-template <int K, int N, class F>
-NJ_DEV void dense_T_inplace(cfp WTp, const float (&dout)[N], float (&io)[K], F f) {
+template <int K, int N, class WP, class F>
+NJ_DEV void dense_T_inplace(WP WTp, const float (&dout)[N], float (&io)[K], F f) {
 #pragma unroll
   for (int i = 0; i < K; ++i) {
     float acc = 0.0f;
@@ -160,8 +168,8 @@ NJ_DEV void dense_T_inplace(cfp WTp, const float (&dout)[N], float (&io)[K], F f
   }
 }
 // same, for the index range [LO, HI) of the input only, into out[HI-LO]
-template <int K, int N, int LO, int HI>
-NJ_DEV void dense_T_range(cfp WTp, const float (&dout)[N], float (&out)[HI - LO]) {
+template <int K, int N, int LO, int HI, class WP>
+NJ_DEV void dense_T_range(WP WTp, const float (&dout)[N], float (&out)[HI - LO]) {
 #pragma unroll
   for (int i = LO; i < HI; ++i) {
     float acc = 0.0f;
@@ -172,11 +180,11 @@ NJ_DEV void dense_T_range(cfp WTp, const float (&dout)[N], float (&out)[HI - LO]
 }
 
 // Forward of one network; a1/a2 receive the (dropout-scaled) hidden activations.
-template <class NL, int ACT, bool DROP>
-NJ_DEV void net_fwd(cfp P0, const float (&in)[NL::IN], float (&out)[NL::OUT],
+template <class NL, int ACT, bool DROP, class WP>
+NJ_DEV void net_fwd(WP P0, const float (&in)[NL::IN], float (&out)[NL::OUT],
                     float (&a1)[NL::W], float (&a2)[NL::W], uint64_t m1,
                     uint64_t m2, float inv_keep) {
-  const cfp P = launder(P0);  // fresh scalar loads per evaluation (no cross-call hoisting)
+  const WP P = launder(P0);  // fresh weight loads per evaluation (no cross-call hoisting)
   if constexpr (NL::NH == 0) {
     dense<NL::IN, NL::OUT>(P + NL::woff(0), P + NL::boff(0), in, out);
   } else {
@@ -219,10 +227,11 @@ NJ_DEV void wave_lds_sync() {
 // padded to 16 B so every lane reads its operands with ds_read_b128; the row
 // stride is an odd number of 16-B slots, so the ds_write_b128 of consecutive
 // lanes (rows) hit distinct banks.
-constexpr int CH = 32;  // chains staged per phase (2 phases per wave)
+// CH = chains staged per phase (64 / CH phases per wave): 32 by default, 16 where the
+// weights share the LDS with the staging rows.
 
-template <int N_, int K_> struct Tile {
-  static constexpr int N = N_, K = K_;
+template <int N_, int K_, int CH_ = 32> struct Tile {
+  static constexpr int N = N_, K = K_, CH = CH_;
   static constexpr int TR = (N + 7) / 8, TC = (K + 1 + 7) / 8;
   static constexpr int TRP = (TR + 3) & ~3, TCP = (TC + 3) & ~3;
   static constexpr int SD = 8 * TRP + 4, SA = 8 * TCP + 4;  // row strides, floats
@@ -325,10 +334,10 @@ template <int N_, int K_> struct Tile {
 };
 
 // Per-network gradient accumulators (register tiles for each layer)
-template <class NL> struct NetAcc {
-  using T0 = Tile<NL::lout(0), NL::lin(0)>;
-  using T1 = Tile<NL::lout(NL::NH >= 1 ? 1 : 0), NL::lin(NL::NH >= 1 ? 1 : 0)>;
-  using T2 = Tile<NL::lout(NL::NH >= 2 ? 2 : 0), NL::lin(NL::NH >= 2 ? 2 : 0)>;
+template <class NL, int CH_ = 32> struct NetAcc {
+  using T0 = Tile<NL::lout(0), NL::lin(0), CH_>;
+  using T1 = Tile<NL::lout(NL::NH >= 1 ? 1 : 0), NL::lin(NL::NH >= 1 ? 1 : 0), CH_>;
+  using T2 = Tile<NL::lout(NL::NH >= 2 ? 2 : 0), NL::lin(NL::NH >= 2 ? 2 : 0), CH_>;
   float a0[T0::NACC];
   float a1[NL::NH >= 1 ? T1::NACC : 1];
   float a2[NL::NH >= 2 ? T2::NACC : 1];
@@ -356,13 +365,13 @@ template <class NL> struct NetAcc {
 //   a1,a2 : hidden activations saved by net_fwd (dropout-scaled); clobbered
 //   din   : gradient w.r.t. inputs [DLO, DHI) (only if DHI > DLO)
 // PT = transposed copy of the parameters (same offsets, weights stored [in][out]).
-template <class NL, int ACT, bool DROP, int DLO, int DHI>
-NJ_DEV void net_bwd(cfp PT0, lfp lds, NetAcc<NL>& g, const float (&in)[NL::IN],
+template <class NL, int ACT, bool DROP, int DLO, int DHI, class WP, int CHN>
+NJ_DEV void net_bwd(WP PT0, lfp lds, NetAcc<NL, CHN>& g, const float (&in)[NL::IN],
                     const float (&dout)[NL::OUT], float (&a1)[NL::W],
                     float (&a2)[NL::W], uint64_t m1, uint64_t m2, float inv_keep,
                     float keep, float (&din)[(DHI > DLO) ? (DHI - DLO) : 1], int lane) {
-  using A = NetAcc<NL>;
-  const cfp PT = launder(PT0);
+  using A = NetAcc<NL, CHN>;
+  const WP PT = launder(PT0);
   if constexpr (NL::NH == 0) {
     A::T0::update(lds, g.a0, dout, in, lane);
     if constexpr (DHI > DLO)

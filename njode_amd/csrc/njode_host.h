@@ -14,8 +14,10 @@ struct CfgOps {
   int P;          // flat parameter count
   int ode_in, enc_in;
   // segment plan
-  hipError_t (*seg_forward)(const KArgs&, bool drop, bool save, hipStream_t);
-  hipError_t (*seg_backward)(const KArgs&, bool drop, hipStream_t);
+  // tails: also evolve every path from its last observation to the end of the schedule
+  // (hT); wlds: ODE weights staged in LDS instead of read through the scalar cache
+  hipError_t (*seg_forward)(const KArgs&, bool drop, bool tails, bool wlds, hipStream_t);
+  hipError_t (*seg_backward)(const KArgs&, bool drop, bool wlds, hipStream_t);
   // lockstep plan
   hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, hipStream_t);
 };

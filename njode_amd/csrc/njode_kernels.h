@@ -65,6 +65,7 @@ struct KArgs {
   const int* item_kbeg;
   const int* item_len;
   const int* order;
+  const int* t_order;  // paths sorted by tail length (descending): hT items
   const long long* base_s;
   // intermediates
   float* h0row;
@@ -86,6 +87,7 @@ struct KArgs {
   float weight;
   int loss_easy;
   int want_path, want_loss;  // lockstep plan: return_path / get_loss (wave-uniform)
+  int save_traj;             // segment plan: checkpoint states for the backward pass
   DropCtx dc;
   float keep;
 };
@@ -117,8 +119,8 @@ template <class C, bool DROP> struct Masks {
 };
 
 // encoder_map (FFNN, models.py:261-276): h = ffnn([tanh(x), mask]) (+ identity)
-template <class C, bool DROP>
-NJ_DEV void encode(cfp Pe, const float (&x)[C::D], const float (&mask)[C::D],
+template <class C, bool DROP, class WP>
+NJ_DEV void encode(WP Pe, const float (&x)[C::D], const float (&mask)[C::D],
                    float (&ein)[C::ENC_IN], float (&a1)[C::W], float (&a2)[C::W],
                    const Masks<C, DROP>& mk, float inv_keep, float (&h)[C::H]) {
 #pragma unroll
@@ -144,8 +146,8 @@ NJ_DEV void encode(cfp Pe, const float (&x)[C::D], const float (&mask)[C::D],
 }
 
 // readout_map: y = ffnn(tanh(h)) (+ identity); th receives tanh(h)
-template <class C, bool DROP>
-NJ_DEV void readout(cfp Pd, const float (&h)[C::H], float (&th)[C::H], float (&a1)[C::W],
+template <class C, bool DROP, class WP>
+NJ_DEV void readout(WP Pd, const float (&h)[C::H], float (&th)[C::H], float (&a1)[C::W],
                     float (&a2)[C::W], const Masks<C, DROP>& mk, float inv_keep,
                     float (&y)[C::DO]) {
 #pragma unroll
@@ -240,59 +242,85 @@ __global__ void __launch_bounds__(64) k_encode_rows(KArgs a) {
   store_vec(is_row ? a.h0row + (size_t)tid * C::H : a.h0start + (size_t)b * C::H, h);
 }
 
-// Per-item descriptor loaded by the ODE kernels (items sorted by length, descending)
+// Per-item descriptor loaded by the ODE kernels.  Segment items (one per observation
+// row, sorted by length, descending) run from the previous observation of their path to
+// their own; tail items (TAIL, one per path) run from the path's last observation to
+// the end of the schedule and only produce hT.
 template <class C> struct Item {
-  int r, b, n, kbeg;
+  int r, b, n, kbeg, prev;
   float tau;
   float tx[C::D];
-  NJ_DEV void load(const KArgs& a, int j, bool valid) {
+  template <bool TAIL> NJ_DEV void load(const KArgs& a, int j, bool valid) {
     const int jj = valid ? j : 0;
-    r = a.order[jj];
-    b = a.obs_idx[r];
-    n = valid ? a.item_len[r] : 0;
-    kbeg = a.item_kbeg[r];
-    const int prev = a.item_prev[r];
-    tau = prev >= 0 ? a.time_f32[a.t_of_row[prev]] : 0.0f;
-    const float* xp = prev >= 0 ? a.X + (size_t)prev * C::D : a.start_X + (size_t)b * C::D;
+    if constexpr (TAIL) {
+      b = r = a.t_order[jj];
+      prev = a.last_row[b];
+      kbeg = prev >= 0 ? a.k_jump[a.t_of_row[prev >= 0 ? prev : 0]] : 0;
+      n = valid ? a.K - kbeg : 0;
+    } else {
+      r = a.order[jj];
+      b = a.obs_idx[r];
+      n = valid ? a.item_len[r] : 0;
+      kbeg = a.item_kbeg[r];
+      prev = a.item_prev[r];
+    }
+    const int pv = prev >= 0 ? prev : 0;
+    const float tprev = a.n_obs > 0 ? a.time_f32[a.t_of_row[pv]] : 0.0f;
+    tau = prev >= 0 ? tprev : 0.0f;
+    const float* xp = prev >= 0 ? a.X + (size_t)pv * C::D : a.start_X + (size_t)b * C::D;
 #pragma unroll
     for (int i = 0; i < C::D; ++i) tx[i] = tanh_f(xp[i]);
   }
   NJ_DEV const float* h0(const KArgs& a) const {
-    const int prev = a.item_prev[r];
     return prev >= 0 ? a.h0row + (size_t)prev * C::H : a.h0start + (size_t)b * C::H;
   }
 };
 
-// B: Euler evolve of every segment from its h0 to the state just before its jump.
-template <class C, bool DROP, bool SAVE>
-__global__ void __launch_bounds__(64) k_ode_fwd_items(KArgs a) {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const bool valid = j < a.n_obs;
+// B: Euler evolve of every item from its h0 to the state just before its jump (or, for
+// tail items, to the end of the schedule).  WLDS: the ODE network's weights are staged
+// in LDS once per 256-thread block and read with wave-uniform ds_reads; otherwise they
+// come through the scalar cache (s_load).
+template <class C, bool DROP, bool TAIL, bool WLDS>
+__global__ void __launch_bounds__(WLDS ? 256 : 64) k_ode_fwd_items(KArgs a) {
+  const bool SAVE = !TAIL && a.save_traj != 0;  // wave-uniform
+  constexpr int NT = WLDS ? 256 : 64;
+  using NL = typename C::Ode;
+  __shared__ __attribute__((aligned(16))) float wl[WLDS ? NL::SIZE : 4];
+  if constexpr (WLDS) {
+    for (int i = threadIdx.x; i < NL::SIZE; i += NT) wl[i] = a.P[C::OFF_ODE + i];
+    __syncthreads();
+  }
+  const int n_items = TAIL ? a.B : a.n_obs;
+  const int j = blockIdx.x * NT + threadIdx.x;
+  const bool valid = j < n_items;
   Item<C> it;
-  it.load(a, j, valid);
+  it.template load<TAIL>(a, j, valid);
   float h[C::H];
   load_vec(it.h0(a), h);
   const int nmax = wave_max(it.n);
-  const cfp Pbase = as_cfp(a.P) + C::OFF_ODE;
+  float* const trash = a.trash + threadIdx.x * C::H;
   for (int s = 0; s < nmax; ++s) {
     const bool active = s < it.n;
     const int k = active ? it.kbeg + s : 0;
-    if constexpr (SAVE) {
-      float* dst = active ? a.traj + (size_t)(a.base_s[s] + j) * C::H
-                          : a.trash + threadIdx.x * C::H;
+    if (SAVE) {
+      float* dst = active ? a.traj + (size_t)(a.base_s[s] + j) * C::H : trash;
       store_vec(dst, h);
     }
     const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
-    const cfp Po = launder(Pbase);
     float in0[C::ODE_IN], a1[C::W], a2[C::W], f[C::H];
     ode_input<C>(it.tx, h, it.tau, t, in0);
     Masks<C, DROP> mk;
     mk.draw(a, a.gid0 + it.b, (uint32_t)k, NET_ODE);
-    net_fwd<typename C::Ode, C::ACT, DROP>(Po, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
+    if constexpr (WLDS)
+      net_fwd<NL, C::ACT, DROP>((lcp)wl, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
+    else
+      net_fwd<NL, C::ACT, DROP>(as_cfp(a.P) + C::OFF_ODE, in0, f, a1, a2, mk.m1, mk.m2,
+                                a.dc.inv_keep);
 #pragma unroll
     for (int i = 0; i < C::H; ++i) h[i] = fmaf(dt, f[i], h[i]);  // dt == 0 when inactive
   }
-  store_vec(valid ? a.h_end + (size_t)it.r * C::H : a.trash + threadIdx.x * C::H, h);
+  float* out = TAIL ? a.hT + (size_t)it.b * C::H : a.h_end + (size_t)it.r * C::H;
+  store_vec(valid ? out : trash, h);
 }
 
 // A (forward): readout before and after the jump, loss term of each row.
@@ -317,16 +345,6 @@ __global__ void __launch_bounds__(64) k_jump_rows(KArgs a) {
   float dy[C::DO], dybj[C::DO];
   const float scale = a.inv_batch / (float)a.n_obs_ot[b];
   a.loss_terms[r] = loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
-}
-
-// hT of the segment plan: the state after each path's last jump (or its start value)
-template <class C> __global__ void k_gather_hT(KArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
-  const int lr = a.last_row[b];
-  const float* src = lr >= 0 ? a.h0row + (size_t)lr * C::H : a.h0start + (size_t)b * C::H;
-#pragma unroll
-  for (int i = 0; i < C::H; ++i) a.hT[(size_t)b * C::H + i] = src[i];
 }
 
 // Gradient of the readout's identity path + tanh at its input
@@ -400,22 +418,38 @@ __global__ void __launch_bounds__(64, 2) k_jump_rows_bwd(KArgs a) {
 }
 
 // C: reverse Euler sweep of every segment (exact discrete adjoint), d loss / d ODE params.
-template <class C, bool DROP>
-__global__ void __launch_bounds__(64, 2) k_ode_bwd_items(KArgs a) {
+// WLDS: weights (W and its transposed copy) staged in LDS once per 256-thread block
+// (4 waves, each with its own staging rows, 16 chains per phase).
+template <class C, bool DROP, bool WLDS>
+__global__ void __launch_bounds__(WLDS ? 256 : 64, 2) k_ode_bwd_items(KArgs a) {
   using NL = typename C::Ode;
-  __shared__ float lds_raw[NetAcc<NL>::LDS_FLOATS];
-  lfp lds = (lfp)lds_raw;
-  const int lane = threadIdx.x;
-  const int wave = blockIdx.x;
-  NetAcc<NL> g;
+  constexpr int CHN = WLDS ? 16 : 32;
+  constexpr int NW = WLDS ? 4 : 1, NT = NW * 64;
+  using Acc = NetAcc<NL, CHN>;
+  __shared__ __attribute__((aligned(16))) float
+      lds_raw[NW * Acc::LDS_FLOATS + (WLDS ? 2 * NL::SIZE : 0)];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * NW + wv;
+  lfp lds = (lfp)lds_raw + wv * Acc::LDS_FLOATS;
+  if constexpr (WLDS) {
+    float* wl = lds_raw + NW * Acc::LDS_FLOATS;
+    for (int i = threadIdx.x; i < NL::SIZE; i += NT) {
+      wl[i] = a.P[C::OFF_ODE + i];
+      wl[NL::SIZE + i] = a.PT[C::OFF_ODE + i];
+    }
+    __syncthreads();
+  }
+  const lcp Wl = (lcp)(lds_raw + NW * Acc::LDS_FLOATS), WTl = Wl + NL::SIZE;
+  const cfp Ws = as_cfp(a.P) + C::OFF_ODE, WTs = as_cfp(a.PT) + C::OFF_ODE;
+  Acc g;
   g.zero();
-  const cfp Po0 = as_cfp(a.P) + C::OFF_ODE, PTo0 = as_cfp(a.PT) + C::OFF_ODE;
+  float* const trash = a.trash + threadIdx.x * C::H;
   const int n_tiles = (a.n_obs + 63) / 64;
   for (int tile = wave; tile < n_tiles; tile += a.n_waves) {
     const int j = tile * 64 + lane;
     const bool valid = j < a.n_obs;
     Item<C> it;
-    it.load(a, j, valid);
+    it.template load<false>(a, j, valid);
     float lam[C::H];
     load_vec(a.lam_end + (size_t)it.r * C::H, lam);  // r is clamped to a valid row
 #pragma unroll
@@ -429,24 +463,30 @@ __global__ void __launch_bounds__(64, 2) k_ode_bwd_items(KArgs a) {
       // contribution is cancelled by dt = 0 below
       load_vec(a.traj + (active ? (size_t)(a.base_s[s] + j) * C::H : 0), h);
       const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
-      const cfp Po = launder(Po0), PTo = launder(PTo0);
       float in0[C::ODE_IN], a1[C::W], a2[C::W], f[C::H], dout[C::H], din[C::H];
       ode_input<C>(it.tx, h, it.tau, t, in0);
       Masks<C, DROP> mk;
       mk.draw(a, a.gid0 + it.b, (uint32_t)k, NET_ODE);
-      net_fwd<NL, C::ACT, DROP>(Po, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
+      if constexpr (WLDS)
+        net_fwd<NL, C::ACT, DROP>(Wl, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
+      else
+        net_fwd<NL, C::ACT, DROP>(Ws, in0, f, a1, a2, mk.m1, mk.m2, a.dc.inv_keep);
       // h' = h + dt f(h): d/df = dt * lam (zero for inactive lanes since dt = 0)
 #pragma unroll
       for (int i = 0; i < C::H; ++i) dout[i] = dt * lam[i];
-      net_bwd<NL, C::ACT, DROP, C::D, C::D + C::H>(PTo, lds, g, in0, dout, a1, a2, mk.m1,
-                                                   mk.m2, a.dc.inv_keep, a.keep, din, lane);
+      if constexpr (WLDS)
+        net_bwd<NL, C::ACT, DROP, C::D, C::D + C::H>(WTl, lds, g, in0, dout, a1, a2, mk.m1,
+                                                     mk.m2, a.dc.inv_keep, a.keep, din, lane);
+      else
+        net_bwd<NL, C::ACT, DROP, C::D, C::D + C::H>(WTs, lds, g, in0, dout, a1, a2, mk.m1,
+                                                     mk.m2, a.dc.inv_keep, a.keep, din, lane);
 #pragma unroll
       for (int i = 0; i < C::H; ++i) {
         const float th = in0[C::D + i];
         lam[i] = fmaf(din[i], 1.0f - th * th, lam[i]);
       }
     }
-    store_vec(valid ? a.lam_start + (size_t)it.r * C::H : a.trash + lane * C::H, lam);
+    store_vec(valid ? a.lam_start + (size_t)it.r * C::H : trash, lam);
   }
   g.flush(a.slab + (size_t)wave * C::P + C::OFF_ODE, lane);
 }

@@ -479,7 +479,8 @@ class NJODE(torch.nn.Module):
         rc = L.njode_forward_f32(
             ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),
             ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
-            hT.data_ptr(), loss.data_ptr() if loss is not None else None,
+            hT.data_ptr() if hT is not None else None,
+            loss.data_ptr() if loss is not None else None,
             path_h.data_ptr() if path_h is not None else None,
             path_y.data_ptr() if path_y is not None else None,
             call.ws.data_ptr(), call.ws.numel(), stream.cuda_stream)
@@ -536,23 +537,23 @@ class NJODE(torch.nn.Module):
     def loss_and_grad(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
                       M=None):
         """Forward + exact gradient in two library calls, no autograd bookkeeping:
-        returns the device loss tensor and fills ``flat_grad()`` (whose slices are
-        the parameters' ``.grad``).  Used by the build's harness and bench."""
+        returns ``(None, loss)`` (device loss tensor; hT is not computed -- it would
+        cost a per-path tail evolve nobody reads) and fills ``flat_grad()`` (whose
+        slices are the parameters' ``.grad``).  Used by the build's harness and bench."""
         grad = self.flat_grad()
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
             M, save_bwd=True)
         dev = start_X.device
-        hT = torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         try:
-            self._run_forward(call, hT, loss, None, None, slot_i)
+            self._run_forward(call, None, loss, None, None, slot_i)   # hT not needed: no tails
             if self._ones is None or self._ones.device != dev:
                 self._ones = torch.ones(1, dtype=torch.float32, device=dev)
             self._run_backward(call, self._ones, grad)
         finally:
             self._release_ws(call)
-        return hT, loss.reshape(())
+        return None, loss.reshape(())
 
     # -- evaluation helpers ---------------------------------------------------------------
     def evaluate(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,

@@ -66,7 +66,15 @@ def run(name, n_paths, dropout, steps, balanced=None, train=True, warmup=2):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--quick', action='store_true')
     a = ap.parse_args()
+    print(json.dumps({'NJODE_WSRC': os.environ.get('NJODE_WSRC', 'lds(default)')}), flush=True)
+    if a.quick:
+        run('default', 20000, 0.1, a.steps)
+        run('balanced-10', 20000, 0.0, a.steps, balanced=10)
+        run('eval-forward', 20000, 0.0, a.steps, train=False)
+        run('B=100', 100, 0.1, 10)
+        sys.exit(0)
     run('default', 20000, 0.1, a.steps)
     run('no-dropout', 20000, 0.0, a.steps)
     run('balanced-10', 20000, 0.0, a.steps, balanced=10)
