@@ -15,30 +15,63 @@ using C = Cfg<NJ_D, NJ_H, NJ_DO, NJ_NH, NJ_W, NJ_ACT, (NJ_MASKED != 0), (NJ_CURT
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, bool wlds,
+hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, int ode,
                                             hipStream_t st);
-hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, bool wlds, hipStream_t st);
+hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st);
+constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED;
+template <bool ON, class CC> struct FragSize { static constexpr int value = 0; };
+template <class CC> struct FragSize<true, CC> { static constexpr int value = MF<CC>::NALL * 64; };
+constexpr int MF_FLOATS = FragSize<HAS_MFMA, C>::value;
+
+// MFMA launches live in templates on the configuration so that `if constexpr` really
+// discards them for shapes the matrix-core kernels are not written for
+template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st) {
+  if constexpr (CC::NH == 2 && !CC::MASKED)
+    k_pack_frags<CC><<<cdiv(MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag);
+}
+template <class CC, bool DROP, bool TAIL> static void launch_mfma_fwd(const KArgs& a, hipStream_t st) {
+  if constexpr (CC::NH == 2 && !CC::MASKED) {
+    const int n_tiles = cdiv(TAIL ? a.B : a.n_obs, 16);
+    k_ode_fwd_mfma<CC, DROP, TAIL><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
+  }
+}
+template <class CC, bool DROP> static void launch_mfma_bwd(const KArgs& a, hipStream_t st) {
+  if constexpr (CC::NH == 2 && !CC::MASKED) k_ode_bwd_mfma<CC, DROP><<<a.n_waves, 64, 0, st>>>(a);
+}
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
                                              hipStream_t st);
 
 #if NJ_PART == 0
-template <bool DROP, bool WLDS>
+template <bool DROP, bool TAIL, int ODE> static void launch_ode_fwd(const KArgs& a, hipStream_t st) {
+  const int n_items = TAIL ? a.B : a.n_obs;
+  if constexpr (ODE == ODE_MFMA) {
+    launch_mfma_fwd<C, DROP, TAIL>(a, st);
+  } else {
+    constexpr bool WLDS = ODE == ODE_VALU_LDS;
+    constexpr int NT = WLDS ? 256 : 64;
+    k_ode_fwd_items<C, DROP, TAIL, WLDS><<<cdiv(n_items, NT), NT, 0, st>>>(a);
+  }
+}
+template <bool DROP, int ODE>
 static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
   if constexpr (C::MASKED) {
     return hipErrorNotSupported;
   } else {
-    constexpr int NT = WLDS ? 256 : 64;
+    if constexpr (ODE == ODE_MFMA) {
+      ProfScope ps("k_pack_frags", st);
+      launch_pack_frags<C>(a, st);
+    }
     {
       ProfScope ps("k_encode_rows", st);
       k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
     }
     {
       ProfScope ps("k_ode_fwd_items", st);
-      k_ode_fwd_items<C, DROP, false, WLDS><<<cdiv(a.n_obs, NT), NT, 0, st>>>(a);
+      launch_ode_fwd<DROP, false, ODE>(a, st);
     }
     if (tails) {
       ProfScope ps("k_ode_fwd_tails", st);
-      k_ode_fwd_items<C, DROP, true, WLDS><<<cdiv(a.B, NT), NT, 0, st>>>(a);
+      launch_ode_fwd<DROP, true, ODE>(a, st);
     }
     {
       ProfScope ps("k_jump_rows", st);
@@ -47,11 +80,17 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     return hipGetLastError();
   }
 }
-hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, bool wlds,
+hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, int ode,
                                             hipStream_t st) {
-  if (drop) return wlds ? seg_forward_t<true, true>(a, tails, st)
-                        : seg_forward_t<true, false>(a, tails, st);
-  return wlds ? seg_forward_t<false, true>(a, tails, st) : seg_forward_t<false, false>(a, tails, st);
+  if (ode == ODE_MFMA && !HAS_MFMA) ode = ODE_VALU;
+  switch (ode * 2 + (drop ? 1 : 0)) {
+    case ODE_MFMA * 2 + 0: return seg_forward_t<false, ODE_MFMA>(a, tails, st);
+    case ODE_MFMA * 2 + 1: return seg_forward_t<true, ODE_MFMA>(a, tails, st);
+    case ODE_VALU_LDS * 2 + 0: return seg_forward_t<false, ODE_VALU_LDS>(a, tails, st);
+    case ODE_VALU_LDS * 2 + 1: return seg_forward_t<true, ODE_VALU_LDS>(a, tails, st);
+    case ODE_VALU * 2 + 1: return seg_forward_t<true, ODE_VALU>(a, tails, st);
+    default: return seg_forward_t<false, ODE_VALU>(a, tails, st);
+  }
 }
 
 const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
@@ -64,13 +103,14 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       C::ENC_IN,
       NJ_CAT(njode_seg_forward_, NJ_ID),
       NJ_CAT(njode_seg_backward_, NJ_ID),
-      NJ_CAT(njode_lock_forward_, NJ_ID)};
+      NJ_CAT(njode_lock_forward_, NJ_ID),
+      HAS_MFMA ? MF_FLOATS : 0};
   return &ops;
 }
 #endif
 
 #if NJ_PART == 1
-template <bool DROP, bool WLDS> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
+template <bool DROP, int ODE> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
   if constexpr (C::MASKED) {
     return hipErrorNotSupported;
   } else {
@@ -80,8 +120,13 @@ template <bool DROP, bool WLDS> static hipError_t seg_backward_t(const KArgs& a,
     }
     {
       ProfScope ps("k_ode_bwd_items", st);
-      if constexpr (WLDS) k_ode_bwd_items<C, DROP, true><<<a.n_waves / 4, 256, 0, st>>>(a);
-      else k_ode_bwd_items<C, DROP, false><<<a.n_waves, 64, 0, st>>>(a);
+      if constexpr (ODE == ODE_MFMA) {
+        launch_mfma_bwd<C, DROP>(a, st);
+      } else if constexpr (ODE == ODE_VALU_LDS) {
+        k_ode_bwd_items<C, DROP, true><<<a.n_waves / 4, 256, 0, st>>>(a);
+      } else {
+        k_ode_bwd_items<C, DROP, false><<<a.n_waves, 64, 0, st>>>(a);
+      }
     }
     {
       ProfScope ps("k_encode_rows_bwd", st);
@@ -90,9 +135,16 @@ template <bool DROP, bool WLDS> static hipError_t seg_backward_t(const KArgs& a,
     return hipGetLastError();
   }
 }
-hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, bool wlds, hipStream_t st) {
-  if (drop) return wlds ? seg_backward_t<true, true>(a, st) : seg_backward_t<true, false>(a, st);
-  return wlds ? seg_backward_t<false, true>(a, st) : seg_backward_t<false, false>(a, st);
+hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st) {
+  if (ode == ODE_MFMA && !HAS_MFMA) ode = ODE_VALU;
+  switch (ode * 2 + (drop ? 1 : 0)) {
+    case ODE_MFMA * 2 + 0: return seg_backward_t<false, ODE_MFMA>(a, st);
+    case ODE_MFMA * 2 + 1: return seg_backward_t<true, ODE_MFMA>(a, st);
+    case ODE_VALU_LDS * 2 + 0: return seg_backward_t<false, ODE_VALU_LDS>(a, st);
+    case ODE_VALU_LDS * 2 + 1: return seg_backward_t<true, ODE_VALU_LDS>(a, st);
+    case ODE_VALU * 2 + 1: return seg_backward_t<true, ODE_VALU>(a, st);
+    default: return seg_backward_t<false, ODE_VALU>(a, st);
+  }
 }
 #endif
 

@@ -3,11 +3,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/njode_hip.h"
-#include "njode_kernels.h"
+#include "njode_mfma.h"
 
 namespace njode {
 
-constexpr int MAX_WAVES = 2048;  // persistent gradient kernels: 256 CUs x 8 waves
+constexpr int MAX_WAVES = 2048;
+// ODE-evolve implementations: matrix cores (default where compiled), VALU with weights
+// through the scalar cache, VALU with LDS-staged weights
+constexpr int ODE_MFMA = 0, ODE_VALU = 1, ODE_VALU_LDS = 2;  // persistent gradient kernels: 256 CUs x 8 waves
 
 struct CfgOps {
   NjodeDims dims;
@@ -15,11 +18,12 @@ struct CfgOps {
   int ode_in, enc_in;
   // segment plan
   // tails: also evolve every path from its last observation to the end of the schedule
-  // (hT); wlds: ODE weights staged in LDS instead of read through the scalar cache
-  hipError_t (*seg_forward)(const KArgs&, bool drop, bool tails, bool wlds, hipStream_t);
-  hipError_t (*seg_backward)(const KArgs&, bool drop, bool wlds, hipStream_t);
+  // (hT); ode: implementation of the ODE-evolve kernels (ODE_*)
+  hipError_t (*seg_forward)(const KArgs&, bool drop, bool tails, int ode, hipStream_t);
+  hipError_t (*seg_backward)(const KArgs&, bool drop, int ode, hipStream_t);
   // lockstep plan
   hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, hipStream_t);
+  int frag_floats;  // size of KArgs::frag (0: no MFMA kernels for this shape)
 };
 
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events

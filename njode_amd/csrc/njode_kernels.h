@@ -38,6 +38,7 @@ struct KArgs {
   // parameters: flat vector and its transposed copy (weights stored [in][out])
   const float* P;
   const float* PT;
+  float* frag;  // MFMA A-fragments of the ODE network (k_pack_frags)
   // batch
   int B, n_obs;
   const float* start_X;

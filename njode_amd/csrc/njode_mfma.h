@@ -1,0 +1,491 @@
+// njode_mfma.h -- ODE-evolve kernels on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// Why: with one chain per lane every Euler step is ~4 500 dependent VALU instructions
+// fed by ~210 scalar weight loads; a single wave needs ~19 us per step and the longest
+// segments (60-70 steps) set the kernel time no matter how many paths run beside them
+// (profiles/r01_v1_smem_variants.jsonl: B=100 costs as much as B=20 000).  On the matrix
+// cores one wave advances 16 chains with 81 MFMAs per step, the weights stay resident in
+// VGPRs as A-fragments (no weight traffic at all inside the time loop) and a step takes
+// ~3-4 k cycles.  f32 MFMA is an exact k-ordered fmaf chain, so results keep fp32 parity.
+//
+// Layout ("D-layout"): a vector of units over the wave's 16 chains is held as registers
+// v[q]; lane l = (g = l >> 4, c = l & 15) holds unit 4q + g of chain c.  That is what
+// MFMA tile mt returns in its 4 accumulator registers (q = 4 mt + r) when A's row i is
+// assigned to unit 16 mt + 4 (i & 3) + (i >> 2), and it is exactly the B operand of
+// k-step q of the next layer (B[k = g][j = c] = unit 4q + g), so activations flow from
+// layer to layer without leaving their registers.  Unit IN of every layer input is the
+// constant 1 (bias column).
+#pragma once
+#include "njode_kernels.h"
+
+namespace njode {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+NJ_DEV f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Fragment tables of the ODE network (NH == 2)
+template <class C> struct MF {
+  static constexpr int H = C::H, D = C::D, W = C::W, IN0 = C::ODE_IN;
+  static constexpr int Q0 = (IN0 + 1 + 3) / 4;  // k-steps of layer 1 (inputs + bias unit)
+  static constexpr int Q1 = (W + 1 + 3) / 4;    // k-steps of layers 2, 3
+  static constexpr int QH = (H + 3) / 4, QW = (W + 3) / 4;
+  static constexpr int MT1 = (W + 15) / 16, MTH = (H + 15) / 16;
+  static constexpr int F1 = 0;                  // W1   [MT1][Q0]
+  static constexpr int F2 = F1 + MT1 * Q0;      // W2   [MT1][Q1]
+  static constexpr int F3 = F2 + MT1 * Q1;      // W3   [MTH][Q1]
+  static constexpr int NFWD = F3 + MTH * Q1;
+  static constexpr int B3 = NFWD;               // W3^T [MT1][QH]
+  static constexpr int B2 = B3 + MT1 * QH;      // W2^T [MT1][QW]
+  static constexpr int B1 = B2 + MT1 * QW;      // W1^T [MTH][QW]  (rows = h inputs)
+  static constexpr int NALL = B1 + MTH * QW;
+  // in0 unit order: [h (H), x (D), tau, tdiff, (tau + tdiff), 1]; reference column of unit u
+  static constexpr int col0(int u) { return u < H ? D + u : (u < H + D ? u - H : u); }
+  static_assert(C::NH == 2, "MFMA ODE kernels are written for two hidden layers");
+};
+
+NJ_DEV int row_unit(int mt, int i) { return 16 * mt + 4 * (i & 3) + (i >> 2); }
+
+// Build the A-fragments of all six products from the flat parameter vector.
+template <class C> __global__ void k_pack_frags(const float* __restrict__ P, float* __restrict__ frag) {
+  using M = MF<C>;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M::NALL * 64) return;
+  const int f = idx >> 6, l = idx & 63, g = l >> 4, c = l & 15;
+  const float* Po = P + C::OFF_ODE;
+  using NL = typename C::Ode;
+  const float *W1 = Po + NL::woff(0), *b1 = Po + NL::boff(0), *W2 = Po + NL::woff(1),
+              *b2 = Po + NL::boff(1), *W3 = Po + NL::woff(2), *b3 = Po + NL::boff(2);
+  float v = 0.0f;
+  if (f < M::F2) {            // W1: out unit = row, in unit = 4q + g
+    const int mt = (f - M::F1) / M::Q0, q = (f - M::F1) % M::Q0;
+    const int uo = row_unit(mt, c), ui = 4 * q + g;
+    if (uo < M::W) v = ui < M::IN0 ? W1[uo * M::IN0 + M::col0(ui)] : (ui == M::IN0 ? b1[uo] : 0.0f);
+  } else if (f < M::F3) {     // W2
+    const int mt = (f - M::F2) / M::Q1, q = (f - M::F2) % M::Q1;
+    const int uo = row_unit(mt, c), ui = 4 * q + g;
+    if (uo < M::W) v = ui < M::W ? W2[uo * M::W + ui] : (ui == M::W ? b2[uo] : 0.0f);
+  } else if (f < M::NFWD) {   // W3
+    const int mt = (f - M::F3) / M::Q1, q = (f - M::F3) % M::Q1;
+    const int uo = row_unit(mt, c), ui = 4 * q + g;
+    if (uo < M::H) v = ui < M::W ? W3[uo * M::W + ui] : (ui == M::W ? b3[uo] : 0.0f);
+  } else if (f < M::B2) {     // W3^T: row = hidden-2 unit, k = output unit
+    const int mt = (f - M::B3) / M::QH, q = (f - M::B3) % M::QH;
+    const int ui = row_unit(mt, c), uo = 4 * q + g;
+    if (ui < M::W && uo < M::H) v = W3[uo * M::W + ui];
+  } else if (f < M::B1) {     // W2^T
+    const int mt = (f - M::B2) / M::QW, q = (f - M::B2) % M::QW;
+    const int ui = row_unit(mt, c), uo = 4 * q + g;
+    if (ui < M::W && uo < M::W) v = W2[uo * M::W + ui];
+  } else {                    // W1^T: row = in0 unit (only the h rows are consumed)
+    const int mt = (f - M::B1) / M::QW, q = (f - M::B1) % M::QW;
+    const int u = row_unit(mt, c), uo = 4 * q + g;
+    if (u < M::IN0 && uo < M::W) v = W1[uo * M::IN0 + M::col0(u)];
+  }
+  frag[idx] = v;
+}
+
+// value of in0 unit u for this lane's chain (compile-time u)
+template <class C, int U>
+NJ_DEV float in0_unit(const float th_q, const float (&tx)[C::D], float tau, float tdiff) {
+  if constexpr (U < C::H) return th_q;
+  else if constexpr (U < C::H + C::D) return tx[U - C::H];
+  else if constexpr (U == C::H + C::D) return tau;
+  else if constexpr (U == C::H + C::D + 1) return tdiff;
+  else if constexpr (C::CURT && U == C::H + C::D + 2) return tau + tdiff;
+  else if constexpr (U == C::ODE_IN) return 1.0f;
+  else return 0.0f;
+}
+template <class C, int Q>
+NJ_DEV void in0_fill(float (&b0)[MF<C>::Q0], const float (&h)[MF<C>::QH], const float (&tx)[C::D],
+                     float tau, float tdiff, int g) {
+  if constexpr (Q < MF<C>::Q0) {
+    float th = 0.0f;
+    if constexpr (4 * Q < C::H) th = tanh_f(h[Q]);
+    const float e0 = in0_unit<C, 4 * Q + 0>(th, tx, tau, tdiff);
+    const float e1 = in0_unit<C, 4 * Q + 1>(th, tx, tau, tdiff);
+    const float e2 = in0_unit<C, 4 * Q + 2>(th, tx, tau, tdiff);
+    const float e3 = in0_unit<C, 4 * Q + 3>(th, tx, tau, tdiff);
+    b0[Q] = g == 0 ? e0 : (g == 1 ? e1 : (g == 2 ? e2 : e3));
+    in0_fill<C, Q + 1>(b0, h, tx, tau, tdiff, g);
+  }
+}
+
+// keep-bits for this lane's NQ units of one hidden layer (lane streams differ per g)
+template <int NQ> NJ_DEV uint32_t keep_bits(uint32_t& s, uint32_t thr16) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int u = 0; u < NQ; u += 2) {
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    m |= (uint32_t)((s & 0xffffu) >= thr16) << u;
+    if (u + 1 < NQ) m |= (uint32_t)((s >> 16) >= thr16) << (u + 1);
+  }
+  return m;
+}
+
+// hidden activation from accumulator tiles: a[q] = act(acc[q / 4][q % 4]) (+dropout),
+// then the bias unit (unit W) is set to 1
+template <class C, bool DROP>
+NJ_DEV void hidden_from_acc(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q1], uint32_t keep,
+                            float inv_keep, int g) {
+  using M = MF<C>;
+#pragma unroll
+  for (int q = 0; q < M::Q1; ++q) {
+    float v = act_f<C::ACT>(acc[q / 4][q % 4]);
+    if constexpr (DROP) v = ((keep >> q) & 1) ? v * inv_keep : 0.0f;
+    av[q] = v;
+  }
+  constexpr int QB = M::W / 4, GB = M::W % 4;
+  av[QB] = g == GB ? 1.0f : av[QB];
+}
+
+// B (MFMA): Euler evolve of every item; 16 items per wave, persistent over tiles.
+template <class C, bool DROP, bool TAIL>
+__global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
+  using M = MF<C>;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  float A1[M::MT1][M::Q0], A2[M::MT1][M::Q1], A3[M::MTH][M::Q1];
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt) {
+#pragma unroll
+    for (int q = 0; q < M::Q0; ++q) A1[mt][q] = a.frag[(M::F1 + mt * M::Q0 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < M::Q1; ++q) A2[mt][q] = a.frag[(M::F2 + mt * M::Q1 + q) * 64 + lane];
+  }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int q = 0; q < M::Q1; ++q) A3[mt][q] = a.frag[(M::F3 + mt * M::Q1 + q) * 64 + lane];
+
+  const bool SAVE = !TAIL && a.save_traj != 0;
+  const int n_items = TAIL ? a.B : a.n_obs;
+  const int n_tiles = (n_items + 15) / 16;
+  float* const trash = a.trash + lane * C::H;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int j = tile * 16 + c;
+    const bool valid = j < n_items;
+    Item<C> it;
+    it.template load<TAIL>(a, j, valid);
+    const float* h0 = it.h0(a);
+    float h[M::QH];
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      h[q] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
+    }
+    const int nmax = wave_max(it.n);
+    for (int s = 0; s < nmax; ++s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      if (SAVE) {
+        float* rec = active ? a.traj + (size_t)(a.base_s[s] + j) * C::H : trash;
+#pragma unroll
+        for (int q = 0; q < M::QH; ++q) {
+          const int u = 4 * q + g;
+          float* dst = u < C::H ? rec + u : trash;
+          *dst = h[q];
+        }
+      }
+      const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
+      float b0[M::Q0];
+      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      uint32_t k1 = 0, k2 = 0;
+      if constexpr (DROP) {
+        const unsigned long long gid = a.gid0 + it.b;
+        uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                                 (uint32_t)k, NET_ODE);
+        k1 = keep_bits<M::Q1>(st, a.dc.thr16);
+        k2 = keep_bits<M::Q1>(st, a.dc.thr16);
+      }
+      f32x4 acc[M::MT1];
+      float a1[M::Q1], a2[M::Q1];
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < M::Q0; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A1[mt][q], b0[q], acc[mt]);
+      hidden_from_acc<C, DROP>(acc, a1, k1, a.dc.inv_keep, g);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A2[mt][q], a1[q], acc[mt]);
+      hidden_from_acc<C, DROP>(acc, a2, k2, a.dc.inv_keep, g);
+      f32x4 acch[M::MTH];
+#pragma unroll
+      for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = mfma4(A3[mt][q], a2[q], acch[mt]);
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) h[q] = fmaf(dt, acch[q / 4][q % 4], h[q]);  // dt = 0: inactive
+    }
+    float* out = valid ? (TAIL ? a.hT + (size_t)it.b * C::H : a.h_end + (size_t)it.r * C::H) : trash;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = h[q];
+    }
+  }
+}
+
+
+// ---- backward ----------------------------------------------------------------------------
+// dW of one layer on the matrix cores: dW[uo][ui] = sum_chain delta[uo][chain] * act[ui][chain]
+// with K = the wave's 16 chains.  Both operands need the chain index on the MFMA k axis,
+// i.e. the transpose of the D-layout, so each vector is staged once in a wave-private LDS
+// image img[unit][chain] (row stride 20 floats: 16-B aligned rows, <= 2-way write
+// conflicts) and read back as [row = lane & 15][chains 4g .. 4g+3] with one ds_read_b128
+// that carries all four k-steps (k-step s of lane group g is chain 4g + s).
+constexpr int IMG_STRIDE = 20;
+constexpr int IMG_ROWS = 64;
+constexpr int IMG_FLOATS = IMG_ROWS * IMG_STRIDE;
+
+template <int NQ> NJ_DEV void img_write(lfp img, const float (&v)[NQ], int g, int c) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) img[(4 * q + g) * IMG_STRIDE + c] = v[q];
+}
+template <int MT, int NT>
+NJ_DEV void dw_accumulate(lfp img_d, lfp img_a, f32x4 (&G)[MT][NT], int g, int c) {
+  f4 bf[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bf[nt] = *(lf4p)(img_a + (16 * nt + c) * IMG_STRIDE + 4 * g);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f4 af = *(lf4p)(img_d + (16 * mt + c) * IMG_STRIDE + 4 * g);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      G[mt][nt] = mfma4(af.x, bf[nt].x, G[mt][nt]);
+      G[mt][nt] = mfma4(af.y, bf[nt].y, G[mt][nt]);
+      G[mt][nt] = mfma4(af.z, bf[nt].z, G[mt][nt]);
+      G[mt][nt] = mfma4(af.w, bf[nt].w, G[mt][nt]);
+    }
+  }
+}
+
+// delta of a hidden layer from the transposed product and the saved activation
+template <class C, bool DROP>
+NJ_DEV void hidden_delta(const f32x4 (&acc)[MF<C>::MT1], const float (&av)[MF<C>::Q1],
+                         float (&dv)[MF<C>::QW], uint32_t keep, float inv_keep, float keepf) {
+#pragma unroll
+  for (int q = 0; q < MF<C>::QW; ++q) {
+    const float gsum = acc[q / 4][q % 4];
+    if constexpr (DROP)
+      dv[q] = ((keep >> q) & 1) ? gsum * inv_keep * dact_f<C::ACT>(av[q] * keepf) : 0.0f;
+    else
+      dv[q] = gsum * dact_f<C::ACT>(av[q]);
+  }
+}
+
+// C (MFMA): reverse Euler sweep of every segment, d loss / d ODE params.
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
+  using M = MF<C>;
+  using NL = typename C::Ode;
+  constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
+  constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
+  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG_FLOATS];
+  lfp img_d = (lfp)lds_raw, img_a = img_d + IMG_FLOATS;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+
+  float A1[M::MT1][M::Q0], A2[M::MT1][M::Q1];
+  float B3[M::MT1][M::QH], B2[M::MT1][M::QW], B1[M::MTH][M::QW];
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt) {
+#pragma unroll
+    for (int q = 0; q < M::Q0; ++q) A1[mt][q] = a.frag[(M::F1 + mt * M::Q0 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < M::Q1; ++q) A2[mt][q] = a.frag[(M::F2 + mt * M::Q1 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) B3[mt][q] = a.frag[(M::B3 + mt * M::QH + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < M::QW; ++q) B2[mt][q] = a.frag[(M::B2 + mt * M::QW + q) * 64 + lane];
+  }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int q = 0; q < M::QW; ++q) B1[mt][q] = a.frag[(M::B1 + mt * M::QW + q) * 64 + lane];
+
+  f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < M::MTH; ++i)
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G3[i][n] = zero4;
+#pragma unroll
+  for (int i = 0; i < M::MT1; ++i) {
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G2[i][n] = zero4;
+#pragma unroll
+    for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
+  }
+  // image rows that no vector writes must be finite (they meet zero deltas / feed
+  // accumulator entries that are never flushed)
+  for (int i = lane; i < 2 * IMG_FLOATS; i += 64) lds_raw[i] = 0.0f;
+  wave_lds_sync();
+
+  float* const trash = a.trash + lane * C::H;
+  const int n_tiles = (a.n_obs + 15) / 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int j = tile * 16 + c;
+    const bool valid = j < a.n_obs;
+    Item<C> it;
+    it.template load<false>(a, j, valid);
+    float lam[M::QH];
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
+      lam[q] = (valid && u < C::H) ? v : 0.0f;
+    }
+    const int nmax = wave_max(it.n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      const float* rec = a.traj + (active ? (size_t)(a.base_s[s] + j) * C::H : 0);
+      float h[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        const float v = rec[u < C::H ? u : 0];
+        h[q] = u < C::H ? v : 0.0f;
+      }
+      const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
+      float b0[M::Q0];
+      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      uint32_t k1 = 0, k2 = 0;
+      if constexpr (DROP) {
+        const unsigned long long gid = a.gid0 + it.b;
+        uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                                 (uint32_t)k, NET_ODE);
+        k1 = keep_bits<M::Q1>(st, a.dc.thr16);
+        k2 = keep_bits<M::Q1>(st, a.dc.thr16);
+      }
+      // ---- recompute the two hidden layers
+      f32x4 acc[M::MT1];
+      float a1[M::Q1], a2[M::Q1];
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::Q0; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A1[mt][q], b0[q], acc[mt]);
+      hidden_from_acc<C, DROP>(acc, a1, k1, a.dc.inv_keep, g);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A2[mt][q], a1[q], acc[mt]);
+      hidden_from_acc<C, DROP>(acc, a2, k2, a.dc.inv_keep, g);
+
+      // ---- layer 3: h' = h + dt f  =>  delta3 = dt * lam (zero for inactive chains)
+      float d3[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
+      img_write<M::QH>(img_d, d3, g, c);
+      img_write<M::Q1>(img_a, a2, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(B3[mt][q], d3[q], acc[mt]);
+      float d2[M::QW];
+      hidden_delta<C, DROP>(acc, a2, d2, k2, a.dc.inv_keep, a.keep);
+      wave_lds_sync();
+
+      // ---- layer 2
+      img_write<M::QW>(img_d, d2, g, c);
+      img_write<M::Q1>(img_a, a1, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(B2[mt][q], d2[q], acc[mt]);
+      float d1[M::QW];
+      hidden_delta<C, DROP>(acc, a1, d1, k1, a.dc.inv_keep, a.keep);
+      wave_lds_sync();
+
+      // ---- layer 1
+      img_write<M::QW>(img_d, d1, g, c);
+      img_write<M::Q0>(img_a, b0, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
+      f32x4 acch[M::MTH];
+#pragma unroll
+      for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = mfma4(B1[mt][q], d1[q], acch[mt]);
+      // adjoint of the state: lam += (W1^T delta1)[h rows] * (1 - tanh(h)^2)
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const float th = b0[q];  // = tanh(h) wherever unit 4q + g < H
+        const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
+        lam[q] = fmaf(acch[q / 4][q % 4], dth, lam[q]);
+      }
+      wave_lds_sync();
+    }
+    float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = lam[q];
+    }
+  }
+
+  // ---- flush the register tiles into this wave's slab (parameter layout)
+  float* slab = a.slab + (size_t)blockIdx.x * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < M::W) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W2[uo * M::W + ui] = G2[mt][nt][r];
+          else if (ui == M::W) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::IN0) W1[uo * M::IN0 + M::col0(ui)] = G1[mt][nt][r];
+          else if (ui == M::IN0) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < C::H) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W3[uo * M::W + ui] = G3[mt][nt][r];
+          else if (ui == M::W) b3[uo] = G3[mt][nt][r];
+        }
+      }
+    }
+}
+
+}  // namespace njode
