@@ -18,26 +18,66 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, int ode,
                                             hipStream_t st);
 hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st);
-constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED;
-template <bool ON, class CC> struct FragSize { static constexpr int value = 0; };
-template <class CC> struct FragSize<true, CC> { static constexpr int value = MF<CC>::NALL * 64; };
-constexpr int MF_FLOATS = FragSize<HAS_MFMA, C>::value;
+constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED && C::DO <= 16 && C::W < 64;
+template <bool ON, class CC> struct FragSize {
+  static constexpr int ode = 0, enc = 0, dec = 0;
+};
+template <class CC> struct FragSize<true, CC> {
+  static constexpr int ode = MF<CC>::NALL * 64;
+  static constexpr int enc = EncS<CC>::type::NALL * 64;
+  static constexpr int dec = DecS<CC>::type::NALL * 64;
+};
+using FS = FragSize<HAS_MFMA, C>;
+constexpr int MF_FLOATS = FS::ode + FS::enc + FS::dec;
 
 // MFMA launches live in templates on the configuration so that `if constexpr` really
 // discards them for shapes the matrix-core kernels are not written for
 template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st) {
-  if constexpr (CC::NH == 2 && !CC::MASKED)
+  if constexpr (HAS_MFMA) {
+    using ES = typename EncS<CC>::type;
+    using DS = typename DecS<CC>::type;
     k_pack_frags<CC><<<cdiv(MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag);
+    k_pack_net<typename CC::Enc, ES><<<cdiv(ES::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_ENC,
+                                                                             a.frag_enc);
+    k_pack_net<typename CC::Dec, DS><<<cdiv(DS::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_DEC,
+                                                                             a.frag_dec);
+  }
+}
+template <class CC, bool DROP> static void launch_mfma_enc(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA) {
+    const int n_tiles = cdiv(a.n_obs + a.B, 16);
+    k_encode_rows_mfma<CC, DROP><<<n_tiles < 2048 ? n_tiles : 2048, 64, 0, st>>>(a);
+  }
+}
+template <class CC, bool DROP> static void launch_mfma_jump(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA) {
+    const int n_tiles = cdiv(a.n_obs, 16);
+    k_jump_rows_mfma<CC, DROP><<<n_tiles < 2048 ? n_tiles : 2048, 64, 0, st>>>(a);
+  }
+}
+template <class CC, bool DROP> static void launch_mfma_rows_bwd(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA) {
+    {
+      ProfScope ps("k_jump_rows_bwd", st);
+      k_jump_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows, 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_ode_bwd_items", st);
+      k_ode_bwd_mfma<CC, DROP><<<a.n_waves_ode, 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_encode_rows_bwd", st);
+      k_encode_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows, 64, 0, st>>>(a);
+    }
+  }
 }
 template <class CC, bool DROP, bool TAIL> static void launch_mfma_fwd(const KArgs& a, hipStream_t st) {
-  if constexpr (CC::NH == 2 && !CC::MASKED) {
+  if constexpr (HAS_MFMA) {
     const int n_tiles = cdiv(TAIL ? a.B : a.n_obs, 16);
     k_ode_fwd_mfma<CC, DROP, TAIL><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
   }
 }
-template <class CC, bool DROP> static void launch_mfma_bwd(const KArgs& a, hipStream_t st) {
-  if constexpr (CC::NH == 2 && !CC::MASKED) k_ode_bwd_mfma<CC, DROP><<<a.n_waves, 64, 0, st>>>(a);
-}
+
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
                                              hipStream_t st);
 
@@ -63,7 +103,8 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     }
     {
       ProfScope ps("k_encode_rows", st);
-      k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
+      if constexpr (ODE == ODE_MFMA) launch_mfma_enc<C, DROP>(a, st);
+      else k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
     }
     {
       ProfScope ps("k_ode_fwd_items", st);
@@ -75,7 +116,8 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     }
     {
       ProfScope ps("k_jump_rows", st);
-      k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
+      if constexpr (ODE == ODE_MFMA) launch_mfma_jump<C, DROP>(a, st);
+      else k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
     }
     return hipGetLastError();
   }
@@ -101,10 +143,14 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       C::P,
       C::ODE_IN,
       C::ENC_IN,
+      C::OFF_ENC,
+      C::OFF_DEC,
       NJ_CAT(njode_seg_forward_, NJ_ID),
       NJ_CAT(njode_seg_backward_, NJ_ID),
       NJ_CAT(njode_lock_forward_, NJ_ID),
-      HAS_MFMA ? MF_FLOATS : 0};
+      MF_FLOATS,
+      FS::ode,
+      FS::ode + FS::enc};
   return &ops;
 }
 #endif
@@ -113,6 +159,9 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
 template <bool DROP, int ODE> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
   if constexpr (C::MASKED) {
     return hipErrorNotSupported;
+  } else if constexpr (ODE == ODE_MFMA) {
+    launch_mfma_rows_bwd<C, DROP>(a, st);
+    return hipGetLastError();
   } else {
     {
       ProfScope ps("k_jump_rows_bwd", st);
@@ -120,13 +169,8 @@ template <bool DROP, int ODE> static hipError_t seg_backward_t(const KArgs& a, h
     }
     {
       ProfScope ps("k_ode_bwd_items", st);
-      if constexpr (ODE == ODE_MFMA) {
-        launch_mfma_bwd<C, DROP>(a, st);
-      } else if constexpr (ODE == ODE_VALU_LDS) {
-        k_ode_bwd_items<C, DROP, true><<<a.n_waves / 4, 256, 0, st>>>(a);
-      } else {
-        k_ode_bwd_items<C, DROP, false><<<a.n_waves, 64, 0, st>>>(a);
-      }
+      if constexpr (ODE == ODE_VALU_LDS) k_ode_bwd_items<C, DROP, true><<<a.n_waves / 4, 256, 0, st>>>(a);
+      else k_ode_bwd_items<C, DROP, false><<<a.n_waves, 64, 0, st>>>(a);
     }
     {
       ProfScope ps("k_encode_rows_bwd", st);

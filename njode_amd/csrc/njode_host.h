@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/njode_hip.h"
-#include "njode_mfma.h"
+#include "njode_mfma_rows.h"
 
 namespace njode {
 
@@ -16,6 +16,7 @@ struct CfgOps {
   NjodeDims dims;
   int P;          // flat parameter count
   int ode_in, enc_in;
+  int off_enc, off_dec;  // start of the encoder / readout slices in the flat vector
   // segment plan
   // tails: also evolve every path from its last observation to the end of the schedule
   // (hT); ode: implementation of the ODE-evolve kernels (ODE_*)
@@ -23,7 +24,8 @@ struct CfgOps {
   hipError_t (*seg_backward)(const KArgs&, bool drop, int ode, hipStream_t);
   // lockstep plan
   hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, hipStream_t);
-  int frag_floats;  // size of KArgs::frag (0: no MFMA kernels for this shape)
+  int frag_floats;  // size of the fragment buffer (0: no MFMA kernels for this shape)
+  int frag_enc_off, frag_dec_off;  // offsets of the encoder / readout fragments in it
 };
 
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events

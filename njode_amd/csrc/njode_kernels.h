@@ -38,7 +38,9 @@ struct KArgs {
   // parameters: flat vector and its transposed copy (weights stored [in][out])
   const float* P;
   const float* PT;
-  float* frag;  // MFMA A-fragments of the ODE network (k_pack_frags)
+  float* frag;      // MFMA A-fragments of the ODE network (k_pack_frags)
+  float* frag_enc;  // ... of the encoder and the readout (k_pack_net)
+  float* frag_dec;
   // batch
   int B, n_obs;
   const float* start_X;
@@ -79,7 +81,9 @@ struct KArgs {
   float* loss_terms;
   float* slab;
   float* trash;  // [64 * max(H, D)] scratch target for the stores of inactive lanes
-  int n_waves;
+  int n_waves;      // persistent gradient kernels (VALU): waves == slab rows
+  int n_waves_ode;  // same for the ODE backward kernel
+  int n_waves_rows; // same for the row backward kernels on the matrix cores
   // outputs
   float* hT;
   float* path_h;

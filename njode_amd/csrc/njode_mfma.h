@@ -46,6 +46,13 @@ template <class C> struct MF {
   static_assert(C::NH == 2, "MFMA ODE kernels are written for two hidden layers");
 };
 
+// Persistent waves walk the length-sorted tiles in boustrophedon ("snake") order: round i
+// gives wave w tile i*G + w, the next round i*G + (G-1-w), so every wave gets long and
+// short tiles alike (static, hence deterministic, yet balanced).
+NJ_DEV int snake_tile(int round, int wave, int n_waves) {
+  return round * n_waves + ((round & 1) ? (n_waves - 1 - wave) : wave);
+}
+
 NJ_DEV int row_unit(int mt, int i) { return 16 * mt + 4 * (i & 3) + (i >> 2); }
 
 // Build the A-fragments of all six products from the flat parameter vector.
@@ -127,18 +134,22 @@ template <int NQ> NJ_DEV uint32_t keep_bits(uint32_t& s, uint32_t thr16) {
 
 // hidden activation from accumulator tiles: a[q] = act(acc[q / 4][q % 4]) (+dropout),
 // then the bias unit (unit W) is set to 1
-template <class C, bool DROP>
-NJ_DEV void hidden_from_acc(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q1], uint32_t keep,
-                            float inv_keep, int g) {
-  using M = MF<C>;
+template <int MT1, int Q1, int W, int ACT, bool DROP>
+NJ_DEV void hidden_from_acc_g(const f32x4 (&acc)[MT1], float (&av)[Q1], uint32_t keep,
+                              float inv_keep, int g) {
 #pragma unroll
-  for (int q = 0; q < M::Q1; ++q) {
-    float v = act_f<C::ACT>(acc[q / 4][q % 4]);
+  for (int q = 0; q < Q1; ++q) {
+    float v = act_f<ACT>(acc[q / 4][q % 4]);
     if constexpr (DROP) v = ((keep >> q) & 1) ? v * inv_keep : 0.0f;
     av[q] = v;
   }
-  constexpr int QB = M::W / 4, GB = M::W % 4;
+  constexpr int QB = W / 4, GB = W % 4;
   av[QB] = g == GB ? 1.0f : av[QB];
+}
+template <class C, bool DROP>
+NJ_DEV void hidden_from_acc(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q1], uint32_t keep,
+                            float inv_keep, int g) {
+  hidden_from_acc_g<MF<C>::MT1, MF<C>::Q1, MF<C>::W, C::ACT, DROP>(acc, av, keep, inv_keep, g);
 }
 
 // B (MFMA): Euler evolve of every item; 16 items per wave, persistent over tiles.
@@ -163,7 +174,9 @@ __global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
   const int n_items = TAIL ? a.B : a.n_obs;
   const int n_tiles = (n_items + 15) / 16;
   float* const trash = a.trash + lane * C::H;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int round = 0; round * (int)gridDim.x < n_tiles; ++round) {
+    const int tile = snake_tile(round, blockIdx.x, gridDim.x);
+    if (tile >= n_tiles) continue;
     const int j = tile * 16 + c;
     const bool valid = j < n_items;
     Item<C> it;
@@ -176,11 +189,30 @@ __global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
       h[q] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
     }
     const int nmax = wave_max(it.n);
+    // per-step scalars are loaded one step ahead (their latency would otherwise sit on
+    // the critical path of every step of a lone wave)
+    float dt_n = 0.0f, t_n = 0.0f;
+    long long base_n = 0;
+    if (nmax > 0) {
+      const int k0 = it.n > 0 ? it.kbeg : 0;
+      dt_n = it.n > 0 ? a.step_dt[k0] : 0.0f;
+      t_n = a.step_t[k0];
+      base_n = SAVE ? a.base_s[0] : 0;
+    }
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
+      const float dt = dt_n, t = t_n;
+      const long long base = base_n;
+      if (s + 1 < nmax) {
+        const bool act_n = s + 1 < it.n;
+        const int kn = act_n ? it.kbeg + s + 1 : 0;
+        dt_n = act_n ? a.step_dt[kn] : 0.0f;
+        t_n = a.step_t[kn];
+        if (SAVE) base_n = a.base_s[s + 1];
+      }
       if (SAVE) {
-        float* rec = active ? a.traj + (size_t)(a.base_s[s] + j) * C::H : trash;
+        float* rec = active ? a.traj + (size_t)(base + j) * C::H : trash;
 #pragma unroll
         for (int q = 0; q < M::QH; ++q) {
           const int u = 4 * q + g;
@@ -188,7 +220,6 @@ __global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
           *dst = h[q];
         }
       }
-      const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
       float b0[M::Q0];
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
       uint32_t k1 = 0, k2 = 0;
@@ -253,34 +284,37 @@ template <int NQ> NJ_DEV void img_write(lfp img, const float (&v)[NQ], int g, in
 }
 template <int MT, int NT>
 NJ_DEV void dw_accumulate(lfp img_d, lfp img_a, f32x4 (&G)[MT][NT], int g, int c) {
-  f4 bf[NT];
+  f4 af[MT], bf[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) af[mt] = *(lf4p)(img_d + (16 * mt + c) * IMG_STRIDE + 4 * g);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bf[nt] = *(lf4p)(img_a + (16 * nt + c) * IMG_STRIDE + 4 * g);
+  // k-step outermost: back-to-back MFMAs never depend on each other
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const f4 af = *(lf4p)(img_d + (16 * mt + c) * IMG_STRIDE + 4 * g);
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      G[mt][nt] = mfma4(af.x, bf[nt].x, G[mt][nt]);
-      G[mt][nt] = mfma4(af.y, bf[nt].y, G[mt][nt]);
-      G[mt][nt] = mfma4(af.z, bf[nt].z, G[mt][nt]);
-      G[mt][nt] = mfma4(af.w, bf[nt].w, G[mt][nt]);
-    }
-  }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) G[mt][nt] = mfma4(af[mt][s], bf[nt][s], G[mt][nt]);
 }
 
 // delta of a hidden layer from the transposed product and the saved activation
+template <int MT1, int Q1, int QW, int ACT, bool DROP>
+NJ_DEV void hidden_delta_g(const f32x4 (&acc)[MT1], const float (&av)[Q1], float (&dv)[QW],
+                           uint32_t keep, float inv_keep, float keepf) {
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const float gsum = acc[q / 4][q % 4];
+    if constexpr (DROP)
+      dv[q] = ((keep >> q) & 1) ? gsum * inv_keep * dact_f<ACT>(av[q] * keepf) : 0.0f;
+    else
+      dv[q] = gsum * dact_f<ACT>(av[q]);
+  }
+}
 template <class C, bool DROP>
 NJ_DEV void hidden_delta(const f32x4 (&acc)[MF<C>::MT1], const float (&av)[MF<C>::Q1],
                          float (&dv)[MF<C>::QW], uint32_t keep, float inv_keep, float keepf) {
-#pragma unroll
-  for (int q = 0; q < MF<C>::QW; ++q) {
-    const float gsum = acc[q / 4][q % 4];
-    if constexpr (DROP)
-      dv[q] = ((keep >> q) & 1) ? gsum * inv_keep * dact_f<C::ACT>(av[q] * keepf) : 0.0f;
-    else
-      dv[q] = gsum * dact_f<C::ACT>(av[q]);
-  }
+  hidden_delta_g<MF<C>::MT1, MF<C>::Q1, MF<C>::QW, C::ACT, DROP>(acc, av, dv, keep, inv_keep, keepf);
 }
 
 // C (MFMA): reverse Euler sweep of every segment, d loss / d ODE params.
@@ -332,7 +366,9 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
 
   float* const trash = a.trash + lane * C::H;
   const int n_tiles = (a.n_obs + 15) / 16;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int round = 0; round * (int)gridDim.x < n_tiles; ++round) {
+    const int tile = snake_tile(round, blockIdx.x, gridDim.x);
+    if (tile >= n_tiles) continue;
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
     Item<C> it;
@@ -345,18 +381,32 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
       lam[q] = (valid && u < C::H) ? v : 0.0f;
     }
     const int nmax = wave_max(it.n);
-    for (int s = nmax - 1; s >= 0; --s) {
-      const bool active = s < it.n;
-      const int k = active ? it.kbeg + s : 0;
-      const float* rec = a.traj + (active ? (size_t)(a.base_s[s] + j) * C::H : 0);
-      float h[M::QH];
+    // state and scalars of a step are loaded while the previous one is processed
+    auto fetch = [&](int s, float (&hh)[M::QH], float& dtt, float& tt) {
+      const bool act = s < it.n;
+      const int kk = act ? it.kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j) * C::H : 0);
 #pragma unroll
       for (int q = 0; q < M::QH; ++q) {
         const int u = 4 * q + g;
         const float v = rec[u < C::H ? u : 0];
-        h[q] = u < C::H ? v : 0.0f;
+        hh[q] = u < C::H ? v : 0.0f;
       }
-      const float dt = active ? a.step_dt[k] : 0.0f, t = a.step_t[k];
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[M::QH], dt_n = 0.0f, t_n = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
+    if (nmax > 0) fetch(nmax - 1, h_n, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      float h[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) h[q] = h_n[q];
+      const float dt = dt_n, t = t_n;
+      if (s > 0) fetch(s - 1, h_n, dt_n, t_n);
       float b0[M::Q0];
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
       uint32_t k1 = 0, k2 = 0;

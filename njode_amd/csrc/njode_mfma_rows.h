@@ -1,0 +1,528 @@
+// njode_mfma_rows.h -- the per-observation-row kernels of the segment plan (encoder,
+// readout + loss, and their backward) on the f32 matrix cores.  Same conventions as
+// njode_mfma.h: 16 rows per wave, vectors in D-layout (lane (g, c) holds unit 4q + g of
+// row c), weights resident in registers as A-fragments, dW through LDS images.
+#pragma once
+#include "njode_mfma.h"
+
+namespace njode {
+
+// shape of one 2-hidden-layer network on the matrix cores
+template <int IN_, int OUT_, int W_> struct MS {
+  static constexpr int IN = IN_, OUT = OUT_, W = W_;
+  static constexpr int Q0 = (IN + 1 + 3) / 4, Q1 = (W + 1 + 3) / 4;
+  static constexpr int QO = (OUT + 3) / 4, QW = (W + 3) / 4, QI = (IN + 3) / 4;
+  static constexpr int MT1 = (W + 15) / 16, MTO = (OUT + 15) / 16, MTI = (IN + 15) / 16;
+  static constexpr int NT1 = (W + 1 + 15) / 16, NT0 = (IN + 1 + 15) / 16;
+  static constexpr int F1 = 0, F2 = F1 + MT1 * Q0, F3 = F2 + MT1 * Q1, NFWD = F3 + MTO * Q1;
+  static constexpr int B3 = NFWD, B2 = B3 + MT1 * QO, B1 = B2 + MT1 * QW, NALL = B1 + MTI * QW;
+  static_assert(W + 1 <= IMG_ROWS && IN + 1 <= IMG_ROWS && OUT <= IMG_ROWS, "LDS image rows");
+};
+
+// A-fragments of all six products of one network (inputs in natural order)
+template <class NL, class S>
+__global__ void k_pack_net(const float* __restrict__ Pn, float* __restrict__ frag) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= S::NALL * 64) return;
+  const int f = idx >> 6, l = idx & 63, g = l >> 4, c = l & 15;
+  const float *W1 = Pn + NL::woff(0), *b1 = Pn + NL::boff(0), *W2 = Pn + NL::woff(1),
+              *b2 = Pn + NL::boff(1), *W3 = Pn + NL::woff(2), *b3 = Pn + NL::boff(2);
+  float v = 0.0f;
+  if (f < S::F2) {
+    const int mt = f / S::Q0, q = f % S::Q0, uo = row_unit(mt, c), ui = 4 * q + g;
+    if (uo < S::W) v = ui < S::IN ? W1[uo * S::IN + ui] : (ui == S::IN ? b1[uo] : 0.0f);
+  } else if (f < S::F3) {
+    const int mt = (f - S::F2) / S::Q1, q = (f - S::F2) % S::Q1, uo = row_unit(mt, c), ui = 4 * q + g;
+    if (uo < S::W) v = ui < S::W ? W2[uo * S::W + ui] : (ui == S::W ? b2[uo] : 0.0f);
+  } else if (f < S::NFWD) {
+    const int mt = (f - S::F3) / S::Q1, q = (f - S::F3) % S::Q1, uo = row_unit(mt, c), ui = 4 * q + g;
+    if (uo < S::OUT) v = ui < S::W ? W3[uo * S::W + ui] : (ui == S::W ? b3[uo] : 0.0f);
+  } else if (f < S::B2) {
+    const int mt = (f - S::B3) / S::QO, q = (f - S::B3) % S::QO, ui = row_unit(mt, c), uo = 4 * q + g;
+    if (ui < S::W && uo < S::OUT) v = W3[uo * S::W + ui];
+  } else if (f < S::B1) {
+    const int mt = (f - S::B2) / S::QW, q = (f - S::B2) % S::QW, ui = row_unit(mt, c), uo = 4 * q + g;
+    if (ui < S::W && uo < S::W) v = W2[uo * S::W + ui];
+  } else {
+    const int mt = (f - S::B1) / S::QW, q = (f - S::B1) % S::QW, ui = row_unit(mt, c), uo = 4 * q + g;
+    if (ui < S::IN && uo < S::W) v = W1[uo * S::IN + ui];
+  }
+  frag[idx] = v;
+}
+
+template <class S> struct FwdFrags {
+  float A1[S::MT1][S::Q0], A2[S::MT1][S::Q1], A3[S::MTO][S::Q1];
+  NJ_DEV void load(const float* frag, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt) {
+#pragma unroll
+      for (int q = 0; q < S::Q0; ++q) A1[mt][q] = frag[(S::F1 + mt * S::Q0 + q) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < S::Q1; ++q) A2[mt][q] = frag[(S::F2 + mt * S::Q1 + q) * 64 + lane];
+    }
+#pragma unroll
+    for (int mt = 0; mt < S::MTO; ++mt)
+#pragma unroll
+      for (int q = 0; q < S::Q1; ++q) A3[mt][q] = frag[(S::F3 + mt * S::Q1 + q) * 64 + lane];
+  }
+};
+template <class S, bool DIN> struct BwdFrags {
+  float B3[S::MT1][S::QO], B2[S::MT1][S::QW], B1[DIN ? S::MTI : 1][S::QW];
+  NJ_DEV void load(const float* frag, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt) {
+#pragma unroll
+      for (int q = 0; q < S::QO; ++q) B3[mt][q] = frag[(S::B3 + mt * S::QO + q) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < S::QW; ++q) B2[mt][q] = frag[(S::B2 + mt * S::QW + q) * 64 + lane];
+    }
+    if constexpr (DIN) {
+#pragma unroll
+      for (int mt = 0; mt < S::MTI; ++mt)
+#pragma unroll
+        for (int q = 0; q < S::QW; ++q) B1[mt][q] = frag[(S::B1 + mt * S::QW + q) * 64 + lane];
+    }
+  }
+};
+template <class S> struct GradTiles {
+  f32x4 G3[S::MTO][S::NT1], G2[S::MT1][S::NT1], G1[S::MT1][S::NT0];
+  NJ_DEV void zero() {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < S::MTO; ++i)
+#pragma unroll
+      for (int n = 0; n < S::NT1; ++n) G3[i][n] = z;
+#pragma unroll
+    for (int i = 0; i < S::MT1; ++i) {
+#pragma unroll
+      for (int n = 0; n < S::NT1; ++n) G2[i][n] = z;
+#pragma unroll
+      for (int n = 0; n < S::NT0; ++n) G1[i][n] = z;
+    }
+  }
+  // store into a slab laid out like the network's parameters (NL offsets)
+  template <class NL> NJ_DEV void flush(float* slab, int g, int c) const {
+    float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+          *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uo = 16 * mt + 4 * g + r;
+        if (uo < S::W) {
+#pragma unroll
+          for (int nt = 0; nt < S::NT1; ++nt) {
+            const int ui = 16 * nt + c;
+            if (ui < S::W) W2[uo * S::W + ui] = G2[mt][nt][r];
+            else if (ui == S::W) b2[uo] = G2[mt][nt][r];
+          }
+#pragma unroll
+          for (int nt = 0; nt < S::NT0; ++nt) {
+            const int ui = 16 * nt + c;
+            if (ui < S::IN) W1[uo * S::IN + ui] = G1[mt][nt][r];
+            else if (ui == S::IN) b1[uo] = G1[mt][nt][r];
+          }
+        }
+      }
+#pragma unroll
+    for (int mt = 0; mt < S::MTO; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uo = 16 * mt + 4 * g + r;
+        if (uo < S::OUT) {
+#pragma unroll
+          for (int nt = 0; nt < S::NT1; ++nt) {
+            const int ui = 16 * nt + c;
+            if (ui < S::W) W3[uo * S::W + ui] = G3[mt][nt][r];
+            else if (ui == S::W) b3[uo] = G3[mt][nt][r];
+          }
+        }
+      }
+  }
+};
+
+template <class S, int ACT, bool DROP>
+NJ_DEV void mnet_fwd(const FwdFrags<S>& F, const float (&b0)[S::Q0], float (&a1)[S::Q1],
+                     float (&a2)[S::Q1], f32x4 (&out)[S::MTO], uint32_t k1, uint32_t k2,
+                     float inv_keep, int g) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[S::MT1];
+#pragma unroll
+  for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
+#pragma unroll
+  for (int q = 0; q < S::Q0; ++q)
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.A1[mt][q], b0[q], acc[mt]);
+  hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a1, k1, inv_keep, g);
+#pragma unroll
+  for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
+#pragma unroll
+  for (int q = 0; q < S::Q1; ++q)
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.A2[mt][q], a1[q], acc[mt]);
+  hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a2, k2, inv_keep, g);
+#pragma unroll
+  for (int mt = 0; mt < S::MTO; ++mt) out[mt] = z;
+#pragma unroll
+  for (int q = 0; q < S::Q1; ++q)
+#pragma unroll
+    for (int mt = 0; mt < S::MTO; ++mt) out[mt] = mfma4(F.A3[mt][q], a2[q], out[mt]);
+}
+
+// backward of one evaluation: dW into G, optionally d/d inputs (pre-tanh factor not
+// applied) in din.  a1 / a2 / b0 as produced by mnet_fwd.  Wave-uniform control flow.
+template <class S, int ACT, bool DROP, bool DIN>
+NJ_DEV void mnet_bwd(const BwdFrags<S, DIN>& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
+                     const float (&dout)[S::QO], const float (&b0)[S::Q0],
+                     const float (&a1)[S::Q1], const float (&a2)[S::Q1], uint32_t k1,
+                     uint32_t k2, float inv_keep, float keepf, f32x4 (&din)[DIN ? S::MTI : 1],
+                     int g, int c) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[S::MT1];
+  img_write<S::QO>(img_d, dout, g, c);
+  img_write<S::Q1>(img_a, a2, g, c);
+  wave_lds_sync();
+  dw_accumulate<S::MTO, S::NT1>(img_d, img_a, G.G3, g, c);
+#pragma unroll
+  for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
+#pragma unroll
+  for (int q = 0; q < S::QO; ++q)
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.B3[mt][q], dout[q], acc[mt]);
+  float d2[S::QW];
+  hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a2, d2, k2, inv_keep, keepf);
+  wave_lds_sync();
+  img_write<S::QW>(img_d, d2, g, c);
+  img_write<S::Q1>(img_a, a1, g, c);
+  wave_lds_sync();
+  dw_accumulate<S::MT1, S::NT1>(img_d, img_a, G.G2, g, c);
+#pragma unroll
+  for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
+#pragma unroll
+  for (int q = 0; q < S::QW; ++q)
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.B2[mt][q], d2[q], acc[mt]);
+  float d1[S::QW];
+  hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a1, d1, k1, inv_keep, keepf);
+  wave_lds_sync();
+  img_write<S::QW>(img_d, d1, g, c);
+  img_write<S::Q0>(img_a, b0, g, c);
+  wave_lds_sync();
+  dw_accumulate<S::MT1, S::NT0>(img_d, img_a, G.G1, g, c);
+  if constexpr (DIN) {
+#pragma unroll
+    for (int mt = 0; mt < S::MTI; ++mt) din[mt] = z;
+#pragma unroll
+    for (int q = 0; q < S::QW; ++q)
+#pragma unroll
+      for (int mt = 0; mt < S::MTI; ++mt) din[mt] = mfma4(Bf.B1[mt][q], d1[q], din[mt]);
+  }
+  wave_lds_sync();
+}
+
+template <bool DROP> NJ_DEV void row_keep_bits(const KArgs& a, unsigned long long gid, uint32_t tkey,
+                                               uint32_t net, int g, int nq, uint32_t& k1,
+                                               uint32_t& k2) {
+  k1 = k2 = 0;
+  if constexpr (DROP) {
+    uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                             tkey, net);
+    k1 = keep_bits<16>(st, a.dc.thr16);
+    k2 = keep_bits<16>(st, a.dc.thr16);
+  }
+  (void)nq;
+}
+
+// value of unit U of a per-lane full vector v[N], selected by the lane group
+template <int Q, int N> NJ_DEV float by_group(const float (&v)[N], int g) {
+  const float e0 = 4 * Q + 0 < N ? v[4 * Q + 0 < N ? 4 * Q + 0 : 0] : 0.0f;
+  const float e1 = 4 * Q + 1 < N ? v[4 * Q + 1 < N ? 4 * Q + 1 : 0] : 0.0f;
+  const float e2 = 4 * Q + 2 < N ? v[4 * Q + 2 < N ? 4 * Q + 2 : 0] : 0.0f;
+  const float e3 = 4 * Q + 3 < N ? v[4 * Q + 3 < N ? 4 * Q + 3 : 0] : 0.0f;
+  return g == 0 ? e0 : (g == 1 ? e1 : (g == 2 ? e2 : e3));
+}
+
+template <int NQ, int N, int Q = 0>
+NJ_DEV void fill_by_group(float (&dq)[NQ], const float (&v)[N], int g) {
+  if constexpr (Q < NQ) {
+    dq[Q] = by_group<Q, N>(v, g);
+    fill_by_group<NQ, N, Q + 1>(dq, v, g);
+  }
+}
+
+// ---- E: encoder on every observation row and every start value ------------------------
+template <class C> struct EncS { using type = MS<C::ENC_IN, C::H, C::W>; };
+template <class C> struct DecS { using type = MS<C::H, C::DO, C::W>; };
+
+// b0 of the encoder: [tanh(x) (D), 1]; xv = x in D-layout
+template <class C, class S>
+NJ_DEV void enc_input(const float* xp, float (&b0)[S::Q0], int g) {
+#pragma unroll
+  for (int q = 0; q < S::Q0; ++q) {
+    const int u = 4 * q + g;
+    const float xv = xp[u < C::D ? u : 0];
+    b0[q] = u < C::D ? tanh_f(xv) : (u == C::D ? 1.0f : 0.0f);
+  }
+}
+// encoder output + identity path (FFNN residual cases) for unit u
+template <class C> NJ_DEV float enc_residual(const float* xp, int u) {
+  if constexpr (C::ENC_CASE == 1) {
+    return xp[u % C::D];
+  } else if constexpr (C::ENC_CASE == 2) {
+    constexpr int mult = C::D / C::H;
+    float s = 0.0f;
+#pragma unroll
+    for (int cc = 0; cc < mult; ++cc) s += xp[cc * C::H + (u < C::H ? u : 0)];
+    return s * (1.0f / mult);
+  } else {
+    return 0.0f;
+  }
+}
+
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64) k_encode_rows_mfma(KArgs a) {
+  using S = typename EncS<C>::type;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  FwdFrags<S> F;
+  F.load(a.frag_enc, lane);
+  const int total = a.n_obs + a.B;
+  const int n_tiles = (total + 15) / 16;
+  float* const trash = a.trash + lane * C::H;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int t0 = tile * 16 + c;
+    const bool valid = t0 < total;
+    const int tid = valid ? t0 : 0;
+    const bool is_row = tid < a.n_obs;
+    const int b = is_row ? a.obs_idx[tid] : tid - a.n_obs;
+    const float* xp = is_row ? a.X + (size_t)tid * C::D : a.start_X + (size_t)b * C::D;
+    float b0[S::Q0], a1[S::Q1], a2[S::Q1];
+    enc_input<C, S>(xp, b0, g);
+    uint32_t k1, k2;
+    row_keep_bits<DROP>(a, a.gid0 + b, is_row ? (uint32_t)a.k_jump[a.t_of_row[tid]] : TKEY_START,
+                        NET_ENC, g, S::Q1, k1, k2);
+    f32x4 out[S::MTO];
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+    float* dstrow = valid ? (is_row ? a.h0row + (size_t)tid * C::H : a.h0start + (size_t)b * C::H)
+                          : trash;
+#pragma unroll
+    for (int q = 0; q < S::QO; ++q) {
+      const int u = 4 * q + g;
+      const float v = out[q / 4][q % 4] + enc_residual<C>(xp, u < C::H ? u : 0);
+      float* dst = u < C::H ? dstrow + u : trash;
+      *dst = v;
+    }
+  }
+}
+
+// readout input [tanh(h) (H), 1] from a row of H floats
+template <class C, class S>
+NJ_DEV void dec_input(const float* hp, float (&b0)[S::Q0], int g) {
+#pragma unroll
+  for (int q = 0; q < S::Q0; ++q) {
+    const int u = 4 * q + g;
+    const float hv = hp[u < C::H ? u : 0];
+    b0[q] = u < C::H ? tanh_f(hv) : (u == C::H ? 1.0f : 0.0f);
+  }
+}
+// full readout vector y[DO] of this lane's row: network output (D-layout, staged through
+// an LDS image) + identity path
+template <class C, class S>
+NJ_DEV void dec_collect(lfp img, const f32x4 (&out)[S::MTO], const float* hp, float (&y)[C::DO],
+                        int g, int c) {
+  float o[S::QO];
+#pragma unroll
+  for (int q = 0; q < S::QO; ++q) o[q] = out[q / 4][q % 4];
+  img_write<S::QO>(img, o, g, c);
+  wave_lds_sync();
+#pragma unroll
+  for (int u = 0; u < C::DO; ++u) {
+    float v = img[u * IMG_STRIDE + c];
+    if constexpr (C::DEC_CASE == 1) {
+      v += hp[u % C::H];
+    } else if constexpr (C::DEC_CASE == 2) {
+      constexpr int mult = C::H / C::DO;
+      float s = 0.0f;
+#pragma unroll
+      for (int cc = 0; cc < mult; ++cc) s += hp[cc * C::DO + u];
+      v += s * (1.0f / mult);
+    }
+    y[u] = v;
+  }
+  wave_lds_sync();
+}
+
+// ---- A (forward): readout before / after the jump and the loss term of each row ---------
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64) k_jump_rows_mfma(KArgs a) {
+  using S = typename DecS<C>::type;
+  static_assert(C::DO <= 16, "row kernels hold the full readout vector per lane");
+  __shared__ __attribute__((aligned(16))) float lds_raw[IMG_FLOATS];
+  lfp img = (lfp)lds_raw;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  FwdFrags<S> F;
+  F.load(a.frag_dec, lane);
+  const int n_tiles = (a.n_obs + 15) / 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int r0 = tile * 16 + c;
+    const bool valid = r0 < a.n_obs;
+    const int r = valid ? r0 : 0;
+    const int b = a.obs_idx[r];
+    const unsigned long long gid = a.gid0 + b;
+    const uint32_t tkey = (uint32_t)a.k_jump[a.t_of_row[r]];
+    const float *he = a.h_end + (size_t)r * C::H, *h0 = a.h0row + (size_t)r * C::H;
+    float b0[S::Q0], a1[S::Q1], a2[S::Q1], y[C::DO], ybj[C::DO], x[C::D], mask[C::D];
+    f32x4 out[S::MTO];
+    uint32_t k1, k2;
+    dec_input<C, S>(he, b0, g);
+    row_keep_bits<DROP>(a, gid, tkey, NET_DEC_BJ, g, S::Q1, k1, k2);
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+    dec_collect<C, S>(img, out, he, ybj, g, c);
+    dec_input<C, S>(h0, b0, g);
+    row_keep_bits<DROP>(a, gid, tkey, NET_DEC, g, S::Q1, k1, k2);
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+    dec_collect<C, S>(img, out, h0, y, g, c);
+    load_vec(a.X + (size_t)r * C::D, x);
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) mask[i] = 1.0f;
+    float dy[C::DO], dybj[C::DO];
+    const float scale = a.inv_batch * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
+    const float term = loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+    if (valid && g == 0) a.loss_terms[r] = term;
+  }
+}
+
+// gradient w.r.t. the readout's input row from din (pre-tanh) and the identity path
+template <class C, class S>
+NJ_DEV void dec_input_grad(const f32x4 (&din)[S::MTI], const float (&b0)[S::Q0],
+                           const float (&dyv)[C::DO], float* dst, float* trash, int g) {
+#pragma unroll
+  for (int q = 0; q < S::QI; ++q) {
+    const int u = 4 * q + g;
+    const float th = b0[q];
+    float v = din[q / 4][q % 4] * (1.0f - th * th);
+    if constexpr (C::DEC_CASE == 1) {
+      // y[j] += h[j % H]: every output j with j % H == u
+#pragma unroll
+      for (int jj = 0; jj < C::DO; ++jj) v += (jj % C::H) == u ? dyv[jj] : 0.0f;
+    } else if constexpr (C::DEC_CASE == 2) {
+      constexpr int mult = C::H / C::DO;
+      float e = 0.0f;
+#pragma unroll
+      for (int jj = 0; jj < C::DO; ++jj) e = (u % C::DO) == jj ? dyv[jj] : e;
+      v += e * (1.0f / mult);
+    }
+    float* p = u < C::H ? dst + u : trash;
+    *p = v;
+  }
+}
+
+// ---- A (backward) ---------------------------------------------------------------------------
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64, 1) k_jump_rows_bwd_mfma(KArgs a) {
+  using S = typename DecS<C>::type;
+  using NL = typename C::Dec;
+  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG_FLOATS];
+  lfp img_d = (lfp)lds_raw, img_a = img_d + IMG_FLOATS;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  FwdFrags<S> F;
+  BwdFrags<S, true> Bf;
+  F.load(a.frag_dec, lane);
+  Bf.load(a.frag_dec, lane);
+  GradTiles<S> G;
+  G.zero();
+  for (int i = lane; i < 2 * IMG_FLOATS; i += 64) lds_raw[i] = 0.0f;
+  wave_lds_sync();
+  float* const trash = a.trash + lane * C::H;
+  const int n_tiles = (a.n_obs + 15) / 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int r0 = tile * 16 + c;
+    const bool valid = r0 < a.n_obs;
+    const int r = valid ? r0 : 0;
+    const int b = a.obs_idx[r];
+    const unsigned long long gid = a.gid0 + b;
+    const uint32_t tkey = (uint32_t)a.k_jump[a.t_of_row[r]];
+    const float *he = a.h_end + (size_t)r * C::H, *h0 = a.h0row + (size_t)r * C::H;
+    float b0[S::Q0], a1[S::Q1], a2[S::Q1], y[C::DO], ybj[C::DO], x[C::D], mask[C::D];
+    float dy[C::DO], dybj[C::DO], dq[S::QO];
+    f32x4 out[S::MTO], din[S::MTI];
+    uint32_t kb1, kb2, k1, k2;
+    // y_bj (activations discarded), then y (activations kept)
+    dec_input<C, S>(he, b0, g);
+    row_keep_bits<DROP>(a, gid, tkey, NET_DEC_BJ, g, S::Q1, kb1, kb2);
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, kb1, kb2, a.dc.inv_keep, g);
+    dec_collect<C, S>(img_d, out, he, ybj, g, c);
+    dec_input<C, S>(h0, b0, g);
+    row_keep_bits<DROP>(a, gid, tkey, NET_DEC, g, S::Q1, k1, k2);
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+    dec_collect<C, S>(img_d, out, h0, y, g, c);
+    load_vec(a.X + (size_t)r * C::D, x);
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) mask[i] = 1.0f;
+    const float scale = (valid ? a.inv_batch : 0.0f) * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
+    loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+    // backward through y = readout(h0row[r])
+    fill_by_group<S::QO, C::DO>(dq, dy, g);
+    mnet_bwd<S, C::ACT, DROP, true>(Bf, G, img_d, img_a, dq, b0, a1, a2, k1, k2, a.dc.inv_keep,
+                                    a.keep, din, g, c);
+    dec_input_grad<C, S>(din, b0, dy, valid ? a.g_h0 + (size_t)r * C::H : trash, trash, g);
+    // backward through y_bj = readout(h_end[r]) (recompute its activations)
+    dec_input<C, S>(he, b0, g);
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, kb1, kb2, a.dc.inv_keep, g);
+    fill_by_group<S::QO, C::DO>(dq, dybj, g);
+    mnet_bwd<S, C::ACT, DROP, true>(Bf, G, img_d, img_a, dq, b0, a1, a2, kb1, kb2,
+                                    a.dc.inv_keep, a.keep, din, g, c);
+    dec_input_grad<C, S>(din, b0, dybj, valid ? a.lam_end + (size_t)r * C::H : trash, trash, g);
+  }
+  G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_DEC, g, c);
+}
+
+// ---- D: d loss / d encoder params -----------------------------------------------------------
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64, 1) k_encode_rows_bwd_mfma(KArgs a) {
+  using S = typename EncS<C>::type;
+  using NL = typename C::Enc;
+  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG_FLOATS];
+  lfp img_d = (lfp)lds_raw, img_a = img_d + IMG_FLOATS;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  FwdFrags<S> F;
+  BwdFrags<S, false> Bf;
+  F.load(a.frag_enc, lane);
+  Bf.load(a.frag_enc, lane);
+  GradTiles<S> G;
+  G.zero();
+  for (int i = lane; i < 2 * IMG_FLOATS; i += 64) lds_raw[i] = 0.0f;
+  wave_lds_sync();
+  const int total = a.n_obs + a.B;
+  const int n_tiles = (total + 15) / 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int t0 = tile * 16 + c;
+    const bool valid = t0 < total;
+    const int tid = valid ? t0 : 0;
+    const bool is_row = tid < a.n_obs;
+    const int b = is_row ? a.obs_idx[tid] : tid - a.n_obs;
+    const float* xp = is_row ? a.X + (size_t)tid * C::D : a.start_X + (size_t)b * C::D;
+    // adjoint of this start state (see k_encode_rows_bwd)
+    const int nxt = is_row ? a.item_next[tid] : a.first_row[b];
+    const int nx = nxt >= 0 ? nxt : 0, rr = is_row ? tid : 0;
+    float gh[S::QO];
+#pragma unroll
+    for (int q = 0; q < S::QO; ++q) {
+      const int u = 4 * q + g, uu = u < C::H ? u : 0;
+      const float l = a.lam_start[(size_t)nx * C::H + uu];
+      const float p = a.g_h0[(size_t)rr * C::H + uu];
+      gh[q] = (valid && u < C::H) ? ((nxt >= 0 ? l : 0.0f) + (is_row ? p : 0.0f)) : 0.0f;
+    }
+    float b0[S::Q0], a1[S::Q1], a2[S::Q1];
+    enc_input<C, S>(xp, b0, g);
+    uint32_t k1, k2;
+    row_keep_bits<DROP>(a, a.gid0 + b, is_row ? (uint32_t)a.k_jump[a.t_of_row[tid]] : TKEY_START,
+                        NET_ENC, g, S::Q1, k1, k2);
+    f32x4 out[S::MTO], din[1];
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+    mnet_bwd<S, C::ACT, DROP, false>(Bf, G, img_d, img_a, gh, b0, a1, a2, k1, k2, a.dc.inv_keep,
+                                     a.keep, din, g, c);
+  }
+  G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_ENC, g, c);
+}
+
+}  // namespace njode
