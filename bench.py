@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 NN = ((50, 'tanh'), (50, 'tanh'))
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_VALU_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: peak FP32 matrix (= FP32 vector)
 
 
 def model_cfg(dropout):
@@ -207,23 +207,37 @@ def main():
             out['kernel_ms'] = per
             dom = max(kern, key=lambda k: kern[k][1])
             dom_ms = kern[dom][1] / max(kern[dom][0], 1)
-            H = 10
-            # algorithmic HBM bytes of the dominant launch:
-            # k_ode_bwd_items reads every saved state (H f32 per Euler step), per item
-            # lam_end + lam_start (2 H f32) and ~32 B of descriptors / x
-            alg = {'k_ode_bwd_items': euler_steps * H * 4 + n_obs * (2 * H * 4 + 32),
-                   'k_ode_fwd_items': euler_steps * H * 4 + n_obs * (2 * H * 4 + 32),
-                   }.get(dom, euler_steps * H * 4)
-            gbs = alg / (dom_ms * 1e-3) / 1e9
-            out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 3),
-                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': round(gbs / HBM_PEAK_GBS, 6), 'traffic': None,
-                               'kernel_ms': round(dom_ms, 5), 'algorithmic_bytes': int(alg)}
+            H, W, IN0 = 10, 50, 13
+            # ALGORITHMIC work of one launch of the ODE kernels, per
+            # Euler step of one path, biases counted as one MAC per output:
+            #   forward : (IN0+1) W + (W+1) W + (W+1) H                      = 3 760 MAC
+            #   backward: recompute L1+L2 3 250 + transposed products 3 500
+            #             + weight-gradient outer products 3 760             = 10 510 MAC
+            macs = {'k_ode_bwd_mfma': 10510, 'k_ode_bwd_items': 10510 + 510,
+                    'k_ode_fwd_mfma': 3760, 'k_ode_fwd_items': 3760}.get(dom)
+            bytes_ = euler_steps * H * 4 + n_obs * (2 * H * 4 + 32)
+            if macs is not None:
+                tf_k = 2.0 * macs * euler_steps / (dom_ms * 1e-3) / 1e12
+                out['roofline'] = {
+                    'bound': 'mfma', 'kernel': dom, 'achieved': round(tf_k, 3),
+                    'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                    'frac': round(tf_k / FP32_MFMA_PEAK_TF, 5), 'traffic': None,
+                    'kernel_ms': round(dom_ms, 5),
+                    'algorithmic_flops': int(2 * macs * euler_steps),
+                    'note': 'f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak = f32 vector peak; '
+                            'useful FLOPs only (tile padding 50->64 not counted)'}
+                gbs = bytes_ / (dom_ms * 1e-3) / 1e9
+                out['hbm_roofline'] = {
+                    'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 3),
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 6),
+                    'algorithmic_bytes': int(bytes_),
+                    'note': '~330 flop/B: the path is compute bound, the HBM fraction is '
+                            'reported because BASELINE.json asks for it'}
             tf = flops / (ms * 1e-3) / 1e12
-            out['valu_roofline'] = {'bound': 'fp32-valu', 'achieved': round(tf, 3),
-                                    'peak': FP32_VALU_PEAK_TF, 'unit': 'TFLOP/s',
-                                    'frac': round(tf / FP32_VALU_PEAK_TF, 5),
-                                    'useful_flops_per_step': int(flops)}
+            out['step_flops'] = {'achieved': round(tf, 3), 'peak': FP32_MFMA_PEAK_TF,
+                                 'unit': 'TFLOP/s', 'frac': round(tf / FP32_MFMA_PEAK_TF, 5),
+                                 'useful_flops_per_step': int(flops),
+                                 'note': 'whole step incl. plan, reductions, Adam, launches'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dt, T)
         print(json.dumps(out))

@@ -58,16 +58,16 @@ template <class CC, bool DROP> static void launch_mfma_jump(const KArgs& a, hipS
 template <class CC, bool DROP> static void launch_mfma_rows_bwd(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     {
-      ProfScope ps("k_jump_rows_bwd", st);
-      k_jump_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows, 64, 0, st>>>(a);
+      ProfScope ps("k_jump_rows_bwd_mfma", st);
+      k_jump_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
     }
     {
-      ProfScope ps("k_ode_bwd_items", st);
-      k_ode_bwd_mfma<CC, DROP><<<a.n_waves_ode, 64, 0, st>>>(a);
+      ProfScope ps("k_ode_bwd_mfma", st);
+      k_ode_bwd_mfma<CC, DROP><<<a.n_waves_ode / 4, 256, 0, st>>>(a);
     }
     {
-      ProfScope ps("k_encode_rows_bwd", st);
-      k_encode_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows, 64, 0, st>>>(a);
+      ProfScope ps("k_encode_rows_bwd_mfma", st);
+      k_encode_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
     }
   }
 }
@@ -102,20 +102,20 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       launch_pack_frags<C>(a, st);
     }
     {
-      ProfScope ps("k_encode_rows", st);
+      ProfScope ps(ODE == ODE_MFMA ? "k_encode_rows_mfma" : "k_encode_rows", st);
       if constexpr (ODE == ODE_MFMA) launch_mfma_enc<C, DROP>(a, st);
       else k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
     }
     {
-      ProfScope ps("k_ode_fwd_items", st);
+      ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma" : "k_ode_fwd_items", st);
       launch_ode_fwd<DROP, false, ODE>(a, st);
     }
     if (tails) {
-      ProfScope ps("k_ode_fwd_tails", st);
+      ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma.tails" : "k_ode_fwd_items.tails", st);
       launch_ode_fwd<DROP, true, ODE>(a, st);
     }
     {
-      ProfScope ps("k_jump_rows", st);
+      ProfScope ps(ODE == ODE_MFMA ? "k_jump_rows_mfma" : "k_jump_rows", st);
       if constexpr (ODE == ODE_MFMA) launch_mfma_jump<C, DROP>(a, st);
       else k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
     }

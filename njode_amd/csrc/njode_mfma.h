@@ -318,33 +318,53 @@ NJ_DEV void hidden_delta(const f32x4 (&acc)[MF<C>::MT1], const float (&av)[MF<C>
 }
 
 // C (MFMA): reverse Euler sweep of every segment, d loss / d ODE params.
+// 256-thread blocks: the A-fragments the sweep needs (W1, W2 and the three transposed
+// products; W3 itself is not needed) live once per block in LDS, so a wave stays under
+// 256 registers and two waves share a SIMD -- one wave's tanh / LDS phases hide behind
+// the other's MFMAs.  Fragment reads are laundered per step so they are not hoisted
+// back into registers.
+template <class C> struct OdeLdsFrags {
+  using M = MF<C>;
+  static constexpr int SKIP = M::NFWD - M::F3;          // W3 fragments are not staged
+  static constexpr int NVEC = M::NALL - SKIP;
+  lfp base, cur;
+  static NJ_DEV void stage(lfp img, const float* frag, int tid, int nthreads) {
+    for (int i = tid; i < M::F3 * 64; i += nthreads) img[i] = frag[i];
+    for (int i = tid; i < (M::NALL - M::NFWD) * 64; i += nthreads)
+      img[M::F3 * 64 + i] = frag[M::NFWD * 64 + i];
+  }
+  NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; }
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lfp)(unsigned long long)v;
+  }
+  NJ_DEV float a1(int mt, int q) const { return cur[(M::F1 + mt * M::Q0 + q) * 64]; }
+  NJ_DEV float a2(int mt, int q) const { return cur[(M::F2 + mt * M::Q1 + q) * 64]; }
+  NJ_DEV float b3(int mt, int q) const { return cur[(M::B3 - SKIP + mt * M::QH + q) * 64]; }
+  NJ_DEV float b2(int mt, int q) const { return cur[(M::B2 - SKIP + mt * M::QW + q) * 64]; }
+  NJ_DEV float b1(int mt, int q) const { return cur[(M::B1 - SKIP + mt * M::QW + q) * 64]; }
+};
+
 template <class C, bool DROP>
-__global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
+__global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
   using M = MF<C>;
   using NL = typename C::Ode;
+  using FR = OdeLdsFrags<C>;
   constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
   constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
-  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG_FLOATS];
-  lfp img_d = (lfp)lds_raw, img_a = img_d + IMG_FLOATS;
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-
-  float A1[M::MT1][M::Q0], A2[M::MT1][M::Q1];
-  float B3[M::MT1][M::QH], B2[M::MT1][M::QW], B1[M::MTH][M::QW];
-#pragma unroll
-  for (int mt = 0; mt < M::MT1; ++mt) {
-#pragma unroll
-    for (int q = 0; q < M::Q0; ++q) A1[mt][q] = a.frag[(M::F1 + mt * M::Q0 + q) * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < M::Q1; ++q) A2[mt][q] = a.frag[(M::F2 + mt * M::Q1 + q) * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < M::QH; ++q) B3[mt][q] = a.frag[(M::B3 + mt * M::QH + q) * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < M::QW; ++q) B2[mt][q] = a.frag[(M::B2 + mt * M::QW + q) * 64 + lane];
-  }
-#pragma unroll
-  for (int mt = 0; mt < M::MTH; ++mt)
-#pragma unroll
-    for (int q = 0; q < M::QW; ++q) B1[mt][q] = a.frag[(M::B1 + mt * M::QW + q) * 64 + lane];
+  __shared__ __attribute__((aligned(16))) float lds_raw[4 * 2 * IMG_FLOATS + FR::NVEC * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+  lfp img_d = (lfp)lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
+  lfp fimg = (lfp)lds_raw + 4 * 2 * IMG_FLOATS;
+  FR::stage(fimg, a.frag, threadIdx.x, 256);
+  // image rows that no vector writes must be finite (they meet zero deltas / feed
+  // accumulator entries that are never flushed)
+  for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  __syncthreads();
+  FR F;
+  F.init(fimg, lane);
 
   f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -359,15 +379,10 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
 #pragma unroll
     for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
   }
-  // image rows that no vector writes must be finite (they meet zero deltas / feed
-  // accumulator entries that are never flushed)
-  for (int i = lane; i < 2 * IMG_FLOATS; i += 64) lds_raw[i] = 0.0f;
-  wave_lds_sync();
-
-  float* const trash = a.trash + lane * C::H;
+  float* const trash = a.trash + threadIdx.x * C::H;
   const int n_tiles = (a.n_obs + 15) / 16;
-  for (int round = 0; round * (int)gridDim.x < n_tiles; ++round) {
-    const int tile = snake_tile(round, blockIdx.x, gridDim.x);
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int tile = snake_tile(round, wave, n_waves);
     if (tile >= n_tiles) continue;
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
@@ -418,6 +433,7 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
         k2 = keep_bits<M::Q1>(st, a.dc.thr16);
       }
       // ---- recompute the two hidden layers
+      F.begin();
       f32x4 acc[M::MT1];
       float a1[M::Q1], a2[M::Q1];
 #pragma unroll
@@ -425,14 +441,14 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
 #pragma unroll
       for (int q = 0; q < M::Q0; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A1[mt][q], b0[q], acc[mt]);
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.a1(mt, q), b0[q], acc[mt]);
       hidden_from_acc<C, DROP>(acc, a1, k1, a.dc.inv_keep, g);
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
 #pragma unroll
       for (int q = 0; q < M::Q1; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A2[mt][q], a1[q], acc[mt]);
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.a2(mt, q), a1[q], acc[mt]);
       hidden_from_acc<C, DROP>(acc, a2, k2, a.dc.inv_keep, g);
 
       // ---- layer 3: h' = h + dt f  =>  delta3 = dt * lam (zero for inactive chains)
@@ -448,7 +464,7 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
 #pragma unroll
       for (int q = 0; q < M::QH; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(B3[mt][q], d3[q], acc[mt]);
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
       float d2[M::QW];
       hidden_delta<C, DROP>(acc, a2, d2, k2, a.dc.inv_keep, a.keep);
       wave_lds_sync();
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
 #pragma unroll
       for (int q = 0; q < M::QW; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(B2[mt][q], d2[q], acc[mt]);
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
       float d1[M::QW];
       hidden_delta<C, DROP>(acc, a1, d1, k1, a.dc.inv_keep, a.keep);
       wave_lds_sync();
@@ -479,7 +495,7 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
 #pragma unroll
       for (int q = 0; q < M::QW; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = mfma4(B1[mt][q], d1[q], acch[mt]);
+        for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = mfma4(F.b1(mt, q), d1[q], acch[mt]);
       // adjoint of the state: lam += (W1^T delta1)[h rows] * (1 - tanh(h)^2)
 #pragma unroll
       for (int q = 0; q < M::QH; ++q) {
@@ -499,7 +515,7 @@ __global__ void __launch_bounds__(64, 1) k_ode_bwd_mfma(KArgs a) {
   }
 
   // ---- flush the register tiles into this wave's slab (parameter layout)
-  float* slab = a.slab + (size_t)blockIdx.x * C::P + C::OFF_ODE;
+  float* slab = a.slab + (size_t)wave * C::P + C::OFF_ODE;
   float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
         *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
 #pragma unroll

@@ -50,6 +50,10 @@ __global__ void k_pack_net(const float* __restrict__ Pn, float* __restrict__ fra
   frag[idx] = v;
 }
 
+// Fragment providers.  Register sets (forward kernels: ~70 VGPRs) and LDS views
+// (gradient kernels: the fragments of one 256-thread block live once in LDS, so each wave
+// stays under 256 registers and two waves fit per SIMD; fragment reads are laundered per
+// evaluation so the compiler does not hoist them back into registers).
 template <class S> struct FwdFrags {
   float A1[S::MT1][S::Q0], A2[S::MT1][S::Q1], A3[S::MTO][S::Q1];
   NJ_DEV void load(const float* frag, int lane) {
@@ -65,24 +69,30 @@ template <class S> struct FwdFrags {
 #pragma unroll
       for (int q = 0; q < S::Q1; ++q) A3[mt][q] = frag[(S::F3 + mt * S::Q1 + q) * 64 + lane];
   }
+  NJ_DEV void begin() const {}
+  NJ_DEV float a1(int mt, int q) const { return A1[mt][q]; }
+  NJ_DEV float a2(int mt, int q) const { return A2[mt][q]; }
+  NJ_DEV float a3(int mt, int q) const { return A3[mt][q]; }
 };
-template <class S, bool DIN> struct BwdFrags {
-  float B3[S::MT1][S::QO], B2[S::MT1][S::QW], B1[DIN ? S::MTI : 1][S::QW];
-  NJ_DEV void load(const float* frag, int lane) {
-#pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) {
-#pragma unroll
-      for (int q = 0; q < S::QO; ++q) B3[mt][q] = frag[(S::B3 + mt * S::QO + q) * 64 + lane];
-#pragma unroll
-      for (int q = 0; q < S::QW; ++q) B2[mt][q] = frag[(S::B2 + mt * S::QW + q) * 64 + lane];
-    }
-    if constexpr (DIN) {
-#pragma unroll
-      for (int mt = 0; mt < S::MTI; ++mt)
-#pragma unroll
-        for (int q = 0; q < S::QW; ++q) B1[mt][q] = frag[(S::B1 + mt * S::QW + q) * 64 + lane];
-    }
+template <class S> struct LdsFrags {
+  lfp base;   // this lane's column of the block's fragment image: base[f * 64]
+  lfp cur;
+  NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; }
+  // copy all S::NALL fragment vectors of the network from global into LDS (whole block)
+  static NJ_DEV void stage(lfp img, const float* frag, int tid, int nthreads) {
+    for (int i = tid; i < S::NALL * 64; i += nthreads) img[i] = frag[i];
   }
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lfp)(unsigned long long)v;
+  }
+  NJ_DEV float a1(int mt, int q) const { return cur[(S::F1 + mt * S::Q0 + q) * 64]; }
+  NJ_DEV float a2(int mt, int q) const { return cur[(S::F2 + mt * S::Q1 + q) * 64]; }
+  NJ_DEV float a3(int mt, int q) const { return cur[(S::F3 + mt * S::Q1 + q) * 64]; }
+  NJ_DEV float b3(int mt, int q) const { return cur[(S::B3 + mt * S::QO + q) * 64]; }
+  NJ_DEV float b2(int mt, int q) const { return cur[(S::B2 + mt * S::QW + q) * 64]; }
+  NJ_DEV float b1(int mt, int q) const { return cur[(S::B1 + mt * S::QW + q) * 64]; }
 };
 template <class S> struct GradTiles {
   f32x4 G3[S::MTO][S::NT1], G2[S::MT1][S::NT1], G1[S::MT1][S::NT0];
@@ -141,44 +151,46 @@ template <class S> struct GradTiles {
   }
 };
 
-template <class S, int ACT, bool DROP>
-NJ_DEV void mnet_fwd(const FwdFrags<S>& F, const float (&b0)[S::Q0], float (&a1)[S::Q1],
+template <class S, int ACT, bool DROP, class FP>
+NJ_DEV void mnet_fwd(FP& F, const float (&b0)[S::Q0], float (&a1)[S::Q1],
                      float (&a2)[S::Q1], f32x4 (&out)[S::MTO], uint32_t k1, uint32_t k2,
                      float inv_keep, int g) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[S::MT1];
+  F.begin();
 #pragma unroll
   for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
 #pragma unroll
   for (int q = 0; q < S::Q0; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.A1[mt][q], b0[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.a1(mt, q), b0[q], acc[mt]);
   hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a1, k1, inv_keep, g);
 #pragma unroll
   for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
 #pragma unroll
   for (int q = 0; q < S::Q1; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.A2[mt][q], a1[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.a2(mt, q), a1[q], acc[mt]);
   hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a2, k2, inv_keep, g);
 #pragma unroll
   for (int mt = 0; mt < S::MTO; ++mt) out[mt] = z;
 #pragma unroll
   for (int q = 0; q < S::Q1; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MTO; ++mt) out[mt] = mfma4(F.A3[mt][q], a2[q], out[mt]);
+    for (int mt = 0; mt < S::MTO; ++mt) out[mt] = mfma4(F.a3(mt, q), a2[q], out[mt]);
 }
 
 // backward of one evaluation: dW into G, optionally d/d inputs (pre-tanh factor not
 // applied) in din.  a1 / a2 / b0 as produced by mnet_fwd.  Wave-uniform control flow.
-template <class S, int ACT, bool DROP, bool DIN>
-NJ_DEV void mnet_bwd(const BwdFrags<S, DIN>& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
+template <class S, int ACT, bool DROP, bool DIN, class FP>
+NJ_DEV void mnet_bwd(FP& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
                      const float (&dout)[S::QO], const float (&b0)[S::Q0],
                      const float (&a1)[S::Q1], const float (&a2)[S::Q1], uint32_t k1,
                      uint32_t k2, float inv_keep, float keepf, f32x4 (&din)[DIN ? S::MTI : 1],
                      int g, int c) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[S::MT1];
+  Bf.begin();
   img_write<S::QO>(img_d, dout, g, c);
   img_write<S::Q1>(img_a, a2, g, c);
   wave_lds_sync();
@@ -188,7 +200,7 @@ NJ_DEV void mnet_bwd(const BwdFrags<S, DIN>& Bf, GradTiles<S>& G, lfp img_d, lfp
 #pragma unroll
   for (int q = 0; q < S::QO; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.B3[mt][q], dout[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.b3(mt, q), dout[q], acc[mt]);
   float d2[S::QW];
   hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a2, d2, k2, inv_keep, keepf);
   wave_lds_sync();
@@ -201,7 +213,7 @@ NJ_DEV void mnet_bwd(const BwdFrags<S, DIN>& Bf, GradTiles<S>& G, lfp img_d, lfp
 #pragma unroll
   for (int q = 0; q < S::QW; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.B2[mt][q], d2[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.b2(mt, q), d2[q], acc[mt]);
   float d1[S::QW];
   hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a1, d1, k1, inv_keep, keepf);
   wave_lds_sync();
@@ -215,7 +227,7 @@ NJ_DEV void mnet_bwd(const BwdFrags<S, DIN>& Bf, GradTiles<S>& G, lfp img_d, lfp
 #pragma unroll
     for (int q = 0; q < S::QW; ++q)
 #pragma unroll
-      for (int mt = 0; mt < S::MTI; ++mt) din[mt] = mfma4(Bf.B1[mt][q], d1[q], din[mt]);
+      for (int mt = 0; mt < S::MTI; ++mt) din[mt] = mfma4(Bf.b1(mt, q), d1[q], din[mt]);
   }
   wave_lds_sync();
 }
@@ -418,23 +430,25 @@ NJ_DEV void dec_input_grad(const f32x4 (&din)[S::MTI], const float (&b0)[S::Q0],
 
 // ---- A (backward) ---------------------------------------------------------------------------
 template <class C, bool DROP>
-__global__ void __launch_bounds__(64, 1) k_jump_rows_bwd_mfma(KArgs a) {
+__global__ void __launch_bounds__(256, 2) k_jump_rows_bwd_mfma(KArgs a) {
   using S = typename DecS<C>::type;
   using NL = typename C::Dec;
-  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG_FLOATS];
-  lfp img_d = (lfp)lds_raw, img_a = img_d + IMG_FLOATS;
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  FwdFrags<S> F;
-  BwdFrags<S, true> Bf;
-  F.load(a.frag_dec, lane);
-  Bf.load(a.frag_dec, lane);
+  __shared__ __attribute__((aligned(16))) float lds_raw[4 * 2 * IMG_FLOATS + S::NALL * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+  lfp img_d = (lfp)lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
+  lfp fimg = (lfp)lds_raw + 4 * 2 * IMG_FLOATS;
+  LdsFrags<S>::stage(fimg, a.frag_dec, threadIdx.x, 256);
+  for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  __syncthreads();
+  LdsFrags<S> F;
+  F.init(fimg, lane);
+  LdsFrags<S>& Bf = F;
   GradTiles<S> G;
   G.zero();
-  for (int i = lane; i < 2 * IMG_FLOATS; i += 64) lds_raw[i] = 0.0f;
-  wave_lds_sync();
-  float* const trash = a.trash + lane * C::H;
+  float* const trash = a.trash + threadIdx.x * C::H;
   const int n_tiles = (a.n_obs + 15) / 16;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = wave; tile < n_tiles; tile += n_waves) {
     const int r0 = tile * 16 + c;
     const bool valid = r0 < a.n_obs;
     const int r = valid ? r0 : 0;
@@ -473,28 +487,30 @@ __global__ void __launch_bounds__(64, 1) k_jump_rows_bwd_mfma(KArgs a) {
                                     a.dc.inv_keep, a.keep, din, g, c);
     dec_input_grad<C, S>(din, b0, dybj, valid ? a.lam_end + (size_t)r * C::H : trash, trash, g);
   }
-  G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_DEC, g, c);
+  G.template flush<NL>(a.slab + (size_t)wave * C::P + C::OFF_DEC, g, c);
 }
 
 // ---- D: d loss / d encoder params -----------------------------------------------------------
 template <class C, bool DROP>
-__global__ void __launch_bounds__(64, 1) k_encode_rows_bwd_mfma(KArgs a) {
+__global__ void __launch_bounds__(256, 2) k_encode_rows_bwd_mfma(KArgs a) {
   using S = typename EncS<C>::type;
   using NL = typename C::Enc;
-  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG_FLOATS];
-  lfp img_d = (lfp)lds_raw, img_a = img_d + IMG_FLOATS;
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  FwdFrags<S> F;
-  BwdFrags<S, false> Bf;
-  F.load(a.frag_enc, lane);
-  Bf.load(a.frag_enc, lane);
+  __shared__ __attribute__((aligned(16))) float lds_raw[4 * 2 * IMG_FLOATS + S::NALL * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+  lfp img_d = (lfp)lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
+  lfp fimg = (lfp)lds_raw + 4 * 2 * IMG_FLOATS;
+  LdsFrags<S>::stage(fimg, a.frag_enc, threadIdx.x, 256);
+  for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  __syncthreads();
+  LdsFrags<S> F;
+  F.init(fimg, lane);
+  LdsFrags<S>& Bf = F;
   GradTiles<S> G;
   G.zero();
-  for (int i = lane; i < 2 * IMG_FLOATS; i += 64) lds_raw[i] = 0.0f;
-  wave_lds_sync();
   const int total = a.n_obs + a.B;
   const int n_tiles = (total + 15) / 16;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (int tile = wave; tile < n_tiles; tile += n_waves) {
     const int t0 = tile * 16 + c;
     const bool valid = t0 < total;
     const int tid = valid ? t0 : 0;
@@ -522,7 +538,7 @@ __global__ void __launch_bounds__(64, 1) k_encode_rows_bwd_mfma(KArgs a) {
     mnet_bwd<S, C::ACT, DROP, false>(Bf, G, img_d, img_a, gh, b0, a1, a2, k1, k2, a.dc.inv_keep,
                                      a.keep, din, g, c);
   }
-  G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_ENC, g, c);
+  G.template flush<NL>(a.slab + (size_t)wave * C::P + C::OFF_ENC, g, c);
 }
 
 }  // namespace njode
