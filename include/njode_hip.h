@@ -155,8 +155,9 @@ int njode_forward_f32(const NjodeDims* dims, const float* params,
  *   grad_loss    [1]   upstream gradient of the scalar loss (device)
  *   grad_params  [P]   OVERWRITTEN with d loss / d params * grad_loss
  *
- * Round-1 coverage: the segment plan (unmasked, use_rnn=False).  Returns
- * NJODE_E_UNSUPPORTED for the lockstep plan.
+ * Both plans are covered: the segment plan runs the reverse sweep per segment on the
+ * matrix cores; the lockstep plan (masked models, schedules with a tail) runs an adjoint
+ * sweep per path followed by parallel weight-gradient kernels.
  */
 int njode_backward_f32(const NjodeDims* dims, const float* params,
                        const NjodeBatch* batch, const NjodeSchedule* sched,

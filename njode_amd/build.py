@@ -5,8 +5,8 @@ The kernels keep each lane's activations in registers, so every model *shape*
 is a separate template instantiation.  ``CONFIGS`` is the table of compiled
 shapes; ``NJODE_EXTRA_CONFIGS`` (env, ``;``-separated
 ``d,H,d_out,n_hidden,width,act,masked,current_t,residual``) appends to it.
-Each shape is compiled as three translation units (segment forward, segment
-backward, lockstep forward) so the build parallelises over the host cores.
+Each shape is compiled as four translation units (segment forward, segment
+backward, lockstep forward, lockstep backward) so the build parallelises over the host cores.
 
 Usage:  python -m njode_amd.build [--force] [-j N]
 """
@@ -85,13 +85,15 @@ def build(force=False, jobs=None, verbose=True):
     common = [cc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c']
     hdr = os.path.join(os.path.dirname(HERE), 'include', 'njode_hip.h')
     kernel_deps = [os.path.join(CSRC, n) for n in
-                   ('njode_cfg.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h')] + [hdr]
+                   ('njode_cfg.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
+                    'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h')] + [hdr]
     api_deps = [os.path.join(CSRC, n) for n in
                 ('njode_api.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
+                 'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                  '_generated_cfgs.inc')] + [hdr]
     tasks = []   # (object, command, digest)
     for i, (d, h, do, nh, w, act, masked, curt, res) in enumerate(cfgs):
-        for part in range(3):
+        for part in range(4):
             obj = os.path.join(OBJ, 'cfg{}_{}.o'.format(i, part))
             defs = ['-DNJ_ID={}'.format(i), '-DNJ_PART={}'.format(part), '-DNJ_D={}'.format(d),
                     '-DNJ_H={}'.format(h), '-DNJ_DO={}'.format(do), '-DNJ_NH={}'.format(nh),
@@ -126,7 +128,7 @@ def build(force=False, jobs=None, verbose=True):
         return out
 
     # heaviest units first (masked 41-dim lockstep kernels dominate the wall time)
-    todo.sort(key=lambda t: 0 if t[0].endswith('_2.o') else 1)
+    todo.sort(key=lambda t: 0 if t[0].endswith(('_2.o', '_3.o')) else 1)
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
         for out in ex.map(compile_one, todo):
             if out.strip() and verbose:

@@ -1,6 +1,6 @@
 // njode_cfg.hip -- one model shape, compiled once per entry of the build table
 // (njode_amd/build.py) and per NJ_PART (0 segment forward + registration,
-// 1 segment backward, 2 lockstep forward) with
+// 1 segment backward, 2 lockstep forward, 3 lockstep backward) with
 //   -DNJ_ID=.. -DNJ_D=.. -DNJ_H=.. -DNJ_DO=.. -DNJ_NH=.. -DNJ_W=.. -DNJ_ACT=..
 //   -DNJ_MASKED=.. -DNJ_CURT=.. -DNJ_RES=.. -DNJ_PART=..
 #include "njode_host.h"
@@ -80,6 +80,7 @@ template <class CC, bool DROP, bool TAIL> static void launch_mfma_fwd(const KArg
 
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
                                              hipStream_t st);
+hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 
 #if NJ_PART == 0
 template <bool DROP, bool TAIL, int ODE> static void launch_ode_fwd(const KArgs& a, hipStream_t st) {
@@ -148,6 +149,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       NJ_CAT(njode_seg_forward_, NJ_ID),
       NJ_CAT(njode_seg_backward_, NJ_ID),
       NJ_CAT(njode_lock_forward_, NJ_ID),
+      NJ_CAT(njode_lock_backward_, NJ_ID),
       MF_FLOATS,
       FS::ode,
       FS::ode + FS::enc};
@@ -203,6 +205,31 @@ template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, hip
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
                                              hipStream_t st) {
   return drop ? lock_t<true>(a, path, loss, st) : lock_t<false>(a, path, loss, st);
+}
+#endif
+
+#if NJ_PART == 3
+template <bool DROP> static hipError_t lock_bwd_t(const KArgs& a, hipStream_t st) {
+  {
+    ProfScope ps("k_paths_bwd_adj", st);
+    k_paths_bwd_adj<C, DROP><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+  }
+  {
+    ProfScope ps("k_ode_dw_pairs", st);
+    k_ode_dw_pairs<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+  }
+  {
+    ProfScope ps("k_dec_dw_rows", st);
+    k_dec_dw_rows<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+  }
+  {
+    ProfScope ps("k_enc_dw_rows", st);
+    k_enc_dw_rows<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+  }
+  return hipGetLastError();
+}
+hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
+  return drop ? lock_bwd_t<true>(a, st) : lock_bwd_t<false>(a, st);
 }
 #endif
 

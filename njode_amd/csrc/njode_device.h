@@ -403,4 +403,35 @@ NJ_DEV void net_bwd(WP PT0, lfp lds, NetAcc<NL, CHN>& g, const float (&in)[NL::I
   if constexpr (DHI > DLO) pin(din);
 }
 
+// Backward of one network evaluation w.r.t. its inputs only (no weight gradients, no
+// LDS, no cross-lane traffic: may run under a divergent branch).  a1 / a2 as saved by
+// net_fwd; clobbered.  din receives d/d in[DLO .. DHI).
+template <class NL, int ACT, bool DROP, int DLO, int DHI, class WP>
+NJ_DEV void net_bwd_inputs(WP PT0, const float (&dout)[NL::OUT], float (&a1)[NL::W],
+                           float (&a2)[NL::W], uint64_t m1, uint64_t m2, float inv_keep,
+                           float keep, float (&din)[DHI - DLO]) {
+  const WP PT = launder(PT0);
+  if constexpr (NL::NH == 0) {
+    dense_T_range<NL::IN, NL::OUT, DLO, DHI>(PT + NL::woff(0), dout, din);
+  } else {
+    auto back = [&](uint64_t m) {
+      return [=](int i, float gsum, float a) -> float {
+        if constexpr (DROP) {
+          return ((m >> i) & 1) ? gsum * inv_keep * dact_f<ACT>(a * keep) : 0.0f;
+        } else {
+          return gsum * dact_f<ACT>(a);
+        }
+      };
+    };
+    if constexpr (NL::NH == 2) {
+      dense_T_inplace<NL::W, NL::OUT>(PT + NL::woff(2), dout, a2, back(m2));  // a2 <- delta2
+      dense_T_inplace<NL::W, NL::W>(PT + NL::woff(1), a2, a1, back(m1));      // a1 <- delta1
+    } else {
+      dense_T_inplace<NL::W, NL::OUT>(PT + NL::woff(1), dout, a1, back(m1));
+    }
+    dense_T_range<NL::IN, NL::W, DLO, DHI>(PT + NL::woff(0), a1, din);
+  }
+  pin(din);
+}
+
 }  // namespace njode

@@ -78,6 +78,19 @@ struct KArgs {
   float* g_h0;
   float* lam_start;
   float* traj;
+  // lockstep plan, saved for its backward: state before every Euler step (and the final
+  // state) [K+1][B][H]; adjoint after every step [K][B][H]; source row of every step
+  // [K][B]; per observation row: readout before / after the jump, their gradients, the
+  // adjoint of the post-jump state; adjoint of every path's start state
+  float* ltraj;
+  float* lam_traj;
+  int* src_row;
+  float* y_row;
+  float* ybj_row;
+  float* g_y;
+  float* g_ybj;
+  float* g_hnew;
+  float* g_hstart;
   float* loss_terms;
   float* slab;
   float* trash;  // [64 * max(H, D)] scratch target for the stores of inactive lanes
@@ -549,6 +562,7 @@ __global__ void __launch_bounds__(64, 2) k_encode_rows_bwd(KArgs a) {
 template <class C, bool DROP>
 __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
   const bool PATH = a.want_path != 0, LOSS = a.want_loss != 0;  // uniform branches
+  const bool SAVE = a.save_traj != 0;
   const int b0 = blockIdx.x * 64 + threadIdx.x;
   const bool valid = b0 < a.B;
   const int b = valid ? b0 : a.B - 1;
@@ -576,6 +590,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
   int cur = a.first_j[b];
   int next_i = a.n_obs > 0 ? a.t_of_row[a.row_by_path[cur >= 0 ? cur : 0]] : 0;
   next_i = cur >= 0 ? next_i : 0x7fffffff;
+  int src = -1;  // row of this path's most recent jump
   int row = 0;
   auto emit = [&](uint32_t tkey) {
     if (PATH) {
@@ -605,6 +620,7 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
         if (has) {
           const int r = a.row_by_path[cur];
           float ybj[C::DO], x[C::D], xin[C::D];
+          if (SAVE) store_vec(a.h_end + (size_t)r * C::H, h);  // state before the jump
           mk.draw(a, gid, (uint32_t)k, NET_DEC_BJ);
           readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, ybj);
           load_vec(a.X + (size_t)r * C::D, x);
@@ -626,6 +642,11 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
             const float scale = a.inv_batch / (float)a.n_obs_ot[b];
             loss_acc += loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
           }
+          if (SAVE) {
+            store_vec(a.y_row + (size_t)r * C::DO, y);
+            store_vec(a.ybj_row + (size_t)r * C::DO, ybj);
+            src = r;
+          }
           // last_X <- Y (masked) or X_obs; tau <- obs time (models.py:481-489)
 #pragma unroll
           for (int q = 0; q < C::D; ++q) tx[q] = tanh_f(C::MASKED ? y[q] : x[q]);
@@ -640,6 +661,10 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
       }
       write_row();
       ++i;
+    }
+    if (SAVE) {  // state before step k (after the jumps applied at k); k == K: final state
+      store_vec(valid ? a.ltraj + ((size_t)k * a.B + b) * C::H : a.trash + threadIdx.x * C::H, h);
+      if (valid && k < a.K) a.src_row[(size_t)k * a.B + b] = src;
     }
     if (k >= a.K) break;
     {

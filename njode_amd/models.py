@@ -546,14 +546,18 @@ class NJODE(torch.nn.Module):
             M, save_bwd=True)
         dev = start_X.device
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        # hT is only skipped on the segment plan (unmasked): there it would cost an extra
+        # per-path tail evolve; the lockstep plan produces it anyway
+        hT = (torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
+              if self.masked else None)
         try:
-            self._run_forward(call, None, loss, None, None, slot_i)   # hT not needed: no tails
+            self._run_forward(call, hT, loss, None, None, slot_i)
             if self._ones is None or self._ones.device != dev:
                 self._ones = torch.ones(1, dtype=torch.float32, device=dev)
             self._run_backward(call, self._ones, grad)
         finally:
             self._release_ws(call)
-        return None, loss.reshape(())
+        return hT, loss.reshape(())
 
     # -- evaluation helpers ---------------------------------------------------------------
     def evaluate(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,

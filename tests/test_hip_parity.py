@@ -169,11 +169,40 @@ def test_larger_batch_loss_and_grads_vs_oracle():
     np.testing.assert_allclose(hT2.cpu().numpy(), h_o.detach().numpy(), atol=ATOL, rtol=RTOL)
 
 
-def test_masked_backward_fails_loudly():
+def test_masked_gradients_match_reference():
+    """BASELINE config 5 shape (PhysioNet-like, d = 41, masked, self-imputation): the
+    lockstep backward (adjoint sweep + parallel weight-gradient kernels) against the
+    reference's autograd gradients; covers the t = 0 jump and an empty time slice."""
     g = Golden('g5_masked')
+    m = hip_model(g.cfg, g.state_dict()).train()      # dropout_rate = 0
+    _, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g['train_loss']), rel=LOSS_RTOL)
+    got = grads_by_name(m)
+    for k, ref in g.group('grad').items():
+        assert rel_l2(got[k], ref) < GRAD_REL_L2, (k, rel_l2(got[k], ref))
+    # fused path on the same batch
+    b = to_dev(g.batch())
+    _, loss2 = m.loss_and_grad(b['times'], b['time_ptr'], b['X'], b['obs_idx'], g.delta_t, g.T,
+                               b['start_X'], b['n_obs_ot'], M=b['M'])
+    assert float(loss2) == pytest.approx(float(g['train_loss']), rel=LOSS_RTOL)
+    flat_ref = np.concatenate([g['grad/' + k].reshape(-1) for k in g.state_dict()])
+    assert rel_l2(m.flat_grad().cpu().numpy(), flat_ref) < GRAD_REL_L2
+
+
+@pytest.mark.parametrize('name', ['g2_bs_grads_B64', 'g6_offgrid_dt', 'g6_power2'])
+def test_lockstep_backward_matches_reference_on_unmasked_models(name):
+    """until_T=True takes the lockstep plan (the schedule has a tail), whose backward is
+    a different set of kernels than the segment plan's; the tail carries no loss, so the
+    gradients must still equal the reference's."""
+    g = Golden(name)
     m = hip_model(g.cfg, g.state_dict()).train()
-    with pytest.raises(NotImplementedError, match='segment plan'):
-        hip_forward(m, g.batch(), g.delta_t, g.T)
+    _, loss = hip_forward(m, g.batch(), g.delta_t, g.T + 0.05, until_T=True)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g['train_loss']), rel=LOSS_RTOL)
+    got = grads_by_name(m)
+    for k, ref in g.group('grad').items():
+        assert rel_l2(got[k], ref) < GRAD_REL_L2, (k, rel_l2(got[k], ref))
 
 
 def test_use_rnn_fails_loudly():
