@@ -19,6 +19,8 @@ hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tai
                                             hipStream_t st);
 hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st);
 constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED && C::DO <= 16 && C::W < 64;
+// the lockstep forward on the matrix cores also covers masked shapes
+constexpr bool HAS_MFMA_LOCK = C::NH == 2 && C::W < 64 && C::H <= 64 && C::DO <= 64;
 template <bool ON, class CC> struct FragSize {
   static constexpr int ode = 0, enc = 0, dec = 0;
 };
@@ -27,7 +29,7 @@ template <class CC> struct FragSize<true, CC> {
   static constexpr int enc = EncS<CC>::type::NALL * 64;
   static constexpr int dec = DecS<CC>::type::NALL * 64;
 };
-using FS = FragSize<HAS_MFMA, C>;
+using FS = FragSize<(HAS_MFMA || HAS_MFMA_LOCK), C>;
 constexpr int MF_FLOATS = FS::ode + FS::enc + FS::dec;
 
 // MFMA launches live in templates on the configuration so that `if constexpr` really
@@ -78,7 +80,7 @@ template <class CC, bool DROP, bool TAIL> static void launch_mfma_fwd(const KArg
   }
 }
 
-hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
+hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss, int ode,
                                              hipStream_t st);
 hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 
@@ -195,16 +197,36 @@ hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode
 #endif
 
 #if NJ_PART == 2
-template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, hipStream_t st) {
-  ProfScope ps("k_paths_fwd", st);
+template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA_LOCK) {
+    using ES = typename EncS<CC>::type;
+    using DS = typename DecS<CC>::type;
+    k_pack_frags<CC><<<cdiv(MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag);
+    k_pack_net<typename CC::Enc, ES><<<cdiv(ES::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_ENC,
+                                                                             a.frag_enc);
+    k_pack_net<typename CC::Dec, DS><<<cdiv(DS::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_DEC,
+                                                                             a.frag_dec);
+  }
+}
+template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA_LOCK) k_paths_fwd_mfma<CC, DROP><<<cdiv(a.B, 32), 128, 0, st>>>(a);
+}
+template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, int ode, hipStream_t st) {
   a.want_path = path ? 1 : 0;
   a.want_loss = loss ? 1 : 0;
-  k_paths_fwd<C, DROP><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+  if (ode == ODE_MFMA && HAS_MFMA_LOCK) {
+    lock_pack_frags<C>(a, st);
+    ProfScope ps("k_paths_fwd_mfma", st);
+    lock_launch_mfma<C, DROP>(a, st);
+  } else {
+    ProfScope ps("k_paths_fwd", st);
+    k_paths_fwd<C, DROP><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+  }
   return hipGetLastError();
 }
-hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss,
+hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss, int ode,
                                              hipStream_t st) {
-  return drop ? lock_t<true>(a, path, loss, st) : lock_t<false>(a, path, loss, st);
+  return drop ? lock_t<true>(a, path, loss, ode, st) : lock_t<false>(a, path, loss, ode, st);
 }
 #endif
 

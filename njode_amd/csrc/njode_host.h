@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "../../include/njode_hip.h"
 #include "njode_lockstep_bwd.h"
-#include "njode_mfma_rows.h"
+#include "njode_mfma_lockstep.h"
 
 namespace njode {
 
@@ -24,7 +24,8 @@ struct CfgOps {
   hipError_t (*seg_forward)(const KArgs&, bool drop, bool tails, int ode, hipStream_t);
   hipError_t (*seg_backward)(const KArgs&, bool drop, int ode, hipStream_t);
   // lockstep plan
-  hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, hipStream_t);
+  // ode: ODE_MFMA runs the matrix-core lockstep kernel where the shape has one
+  hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, int ode, hipStream_t);
   hipError_t (*lock_backward)(const KArgs&, bool drop, hipStream_t);
   int frag_floats;  // size of the fragment buffer (0: no MFMA kernels for this shape)
   int frag_enc_off, frag_dec_off;  // offsets of the encoder / readout fragments in it

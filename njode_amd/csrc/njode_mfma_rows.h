@@ -16,7 +16,6 @@ template <int IN_, int OUT_, int W_> struct MS {
   static constexpr int NT1 = (W + 1 + 15) / 16, NT0 = (IN + 1 + 15) / 16;
   static constexpr int F1 = 0, F2 = F1 + MT1 * Q0, F3 = F2 + MT1 * Q1, NFWD = F3 + MTO * Q1;
   static constexpr int B3 = NFWD, B2 = B3 + MT1 * QO, B1 = B2 + MT1 * QW, NALL = B1 + MTI * QW;
-  static_assert(W + 1 <= IMG_ROWS && IN + 1 <= IMG_ROWS && OUT <= IMG_ROWS, "LDS image rows");
 };
 
 // A-fragments of all six products of one network (inputs in natural order)
@@ -188,6 +187,8 @@ NJ_DEV void mnet_bwd(FP& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
                      const float (&a1)[S::Q1], const float (&a2)[S::Q1], uint32_t k1,
                      uint32_t k2, float inv_keep, float keepf, f32x4 (&din)[DIN ? S::MTI : 1],
                      int g, int c) {
+  static_assert(S::W + 1 <= IMG_ROWS && S::IN + 1 <= IMG_ROWS && S::OUT <= IMG_ROWS,
+                "dW staging images hold at most IMG_ROWS units");
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[S::MT1];
   Bf.begin();
