@@ -23,6 +23,7 @@
  * SURVEY.md section 8 a12):
  *     ode_f.f.{0,3,6}.{weight,bias}, encoder_map.ffnn.{0,3,6}.{weight,bias},
  *     readout_map.ffnn.{0,3,6}.{weight,bias}
+ *     [, obs_c.gru_d.{weight_ih,weight_hh,bias_ih,bias_hh} if use_rnn]
  * each weight in nn.Linear layout [out][in] row-major, each bias [out].  With
  * `bias=False` the bias slots are present and must be zero.
  */
@@ -53,6 +54,7 @@ typedef struct ihipStream_t* njodeStream_t; /* == hipStream_t */
 #define NJODE_F_INPUT_CURRENT_T 0x2  /* options['input_current_t']  models.py:334-337 */
 #define NJODE_F_RESIDUAL 0x4         /* options['residual_enc_dec'] models.py:329-332 */
 #define NJODE_F_LOSS_EASY 0x8        /* which_loss == 'easy'        models.py:109-126 */
+#define NJODE_F_USE_RNN 0x10         /* use_rnn: GRU jump           models.py:202-217 */
 
 typedef struct NjodeDims {
   int32_t input_size;  /* d                                                      */

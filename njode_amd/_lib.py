@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libnjode_hip.so')
 NJODE_OK = 0
 E_UNSUPPORTED, E_BADARG, E_WORKSPACE, E_HIP = 1, 2, 3, 4
 ACT_TANH, ACT_RELU = 0, 1
-F_MASKED, F_INPUT_CURRENT_T, F_RESIDUAL, F_LOSS_EASY = 0x1, 0x2, 0x4, 0x8
+F_MASKED, F_INPUT_CURRENT_T, F_RESIDUAL, F_LOSS_EASY, F_USE_RNN = 0x1, 0x2, 0x4, 0x8, 0x10
 C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD = 0x1, 0x2, 0x4, 0x8
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',

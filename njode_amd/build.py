@@ -4,7 +4,7 @@ Build libnjode_hip.so (gfx950) in-tree with hipcc.
 The kernels keep each lane's activations in registers, so every model *shape*
 is a separate template instantiation.  ``CONFIGS`` is the table of compiled
 shapes; ``NJODE_EXTRA_CONFIGS`` (env, ``;``-separated
-``d,H,d_out,n_hidden,width,act,masked,current_t,residual``) appends to it.
+``d,H,d_out,n_hidden,width,act,masked,current_t,residual,use_rnn``) appends to it.
 Each shape is compiled as four translation units (segment forward, segment
 backward, lockstep forward, lockstep backward) so the build parallelises over the host cores.
 
@@ -24,16 +24,17 @@ LIB = os.path.join(HERE, 'libnjode_hip.so')
 ARCH = 'gfx950'
 
 TANH, RELU = 0, 1
-# (d, H, d_out, n_hidden, width, act, masked, input_current_t, residual)
+# (d, H, d_out, n_hidden, width, act, masked, input_current_t, residual, use_rnn)
 CONFIGS = [
-    (1, 10, 1, 2, 50, TANH, 0, 0, 1),    # demo.py: BlackScholes / OU / Heston (configs 1-4)
-    (1, 10, 1, 2, 50, TANH, 0, 1, 1),    # options['input_current_t']
-    (1, 10, 1, 2, 50, TANH, 0, 0, 0),    # options['residual_enc_dec'] = False
-    (2, 10, 2, 2, 50, TANH, 0, 0, 1),    # func_appl_X=['power-2']
-    (1, 10, 1, 2, 20, RELU, 0, 0, 1),    # relu nets
-    (1, 10, 1, 0, 0, TANH, 0, 0, 1),     # nn_desc=None (single Linear per net)
-    (41, 41, 41, 2, 50, TANH, 1, 0, 1),  # PhysioNet shape, reference setting (H=41 residual)
-    (41, 50, 41, 2, 50, TANH, 1, 0, 0),  # PhysioNet shape, BASELINE config 5 wording (H=50)
+    (1, 10, 1, 2, 50, TANH, 0, 0, 1, 0),    # demo.py: BlackScholes / OU / Heston (configs 1-4)
+    (1, 10, 1, 2, 50, TANH, 0, 1, 1, 0),    # options['input_current_t']
+    (1, 10, 1, 2, 50, TANH, 0, 0, 0, 0),    # options['residual_enc_dec'] = False
+    (2, 10, 2, 2, 50, TANH, 0, 0, 1, 0),    # func_appl_X=['power-2']
+    (1, 10, 1, 2, 20, RELU, 0, 0, 1, 0),    # relu nets
+    (1, 10, 1, 0, 0, TANH, 0, 0, 1, 0),     # nn_desc=None (single Linear per net)
+    (41, 41, 41, 2, 50, TANH, 1, 0, 1, 0),  # PhysioNet shape, reference setting (H=41 residual)
+    (41, 50, 41, 2, 50, TANH, 1, 0, 0, 0),  # PhysioNet shape, BASELINE config 5 wording (H=50)
+    (1, 10, 1, 2, 50, TANH, 0, 0, 1, 1),    # use_rnn=True: GRU jump (models.py:202-217)
 ]
 
 
@@ -42,8 +43,8 @@ def all_configs():
     extra = os.environ.get('NJODE_EXTRA_CONFIGS', '').strip()
     for item in filter(None, extra.split(';')):
         t = tuple(int(x) for x in item.split(','))
-        if len(t) != 9:
-            raise ValueError('NJODE_EXTRA_CONFIGS entries need 9 integers: ' + item)
+        if len(t) != 10:
+            raise ValueError('NJODE_EXTRA_CONFIGS entries need 10 integers: ' + item)
         if t not in cfgs:
             cfgs.append(t)
     return cfgs
@@ -92,14 +93,14 @@ def build(force=False, jobs=None, verbose=True):
                  'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                  '_generated_cfgs.inc')] + [hdr]
     tasks = []   # (object, command, digest)
-    for i, (d, h, do, nh, w, act, masked, curt, res) in enumerate(cfgs):
+    for i, (d, h, do, nh, w, act, masked, curt, res, rnn) in enumerate(cfgs):
         for part in range(4):
             obj = os.path.join(OBJ, 'cfg{}_{}.o'.format(i, part))
             defs = ['-DNJ_ID={}'.format(i), '-DNJ_PART={}'.format(part), '-DNJ_D={}'.format(d),
                     '-DNJ_H={}'.format(h), '-DNJ_DO={}'.format(do), '-DNJ_NH={}'.format(nh),
                     '-DNJ_W={}'.format(max(w, 1)), '-DNJ_ACT={}'.format(act),
                     '-DNJ_MASKED={}'.format(masked), '-DNJ_CURT={}'.format(curt),
-                    '-DNJ_RES={}'.format(res), '-DNJ_ACC_TANH={}'.format(masked)]
+                    '-DNJ_RES={}'.format(res), '-DNJ_ACC_TANH={}'.format(masked), '-DNJ_RNN={}'.format(rnn)]
             cmd = common + defs + [os.path.join(CSRC, 'njode_cfg.hip'), '-o', obj]
             tasks.append((obj, cmd, _digest(kernel_deps, ' '.join(cmd))))
     api_obj = os.path.join(OBJ, 'api.o')

@@ -10,17 +10,20 @@
 
 namespace njode {
 
+#ifndef NJ_RNN
+#define NJ_RNN 0
+#endif
 using C = Cfg<NJ_D, NJ_H, NJ_DO, NJ_NH, NJ_W, NJ_ACT, (NJ_MASKED != 0), (NJ_CURT != 0),
-              (NJ_RES != 0)>;
+              (NJ_RES != 0), (NJ_RNN != 0)>;
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 hipError_t NJ_CAT(njode_seg_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, int ode,
                                             hipStream_t st);
 hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st);
-constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED && C::DO <= 16 && C::W < 64;
+constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED && !C::RNN && C::DO <= 16 && C::W < 64;
 // the lockstep forward on the matrix cores also covers masked shapes
-constexpr bool HAS_MFMA_LOCK = C::NH == 2 && C::W < 64 && C::H <= 64 && C::DO <= 64;
+constexpr bool HAS_MFMA_LOCK = C::NH == 2 && !C::RNN && C::W < 64 && C::H <= 64 && C::DO <= 64;
 template <bool ON, class CC> struct FragSize {
   static constexpr int ode = 0, enc = 0, dec = 0;
 };
@@ -97,7 +100,7 @@ template <bool DROP, bool TAIL, int ODE> static void launch_ode_fwd(const KArgs&
 }
 template <bool DROP, int ODE>
 static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
-  if constexpr (C::MASKED) {
+  if constexpr (C::MASKED || C::RNN) {
     return hipErrorNotSupported;
   } else {
     if constexpr (ODE == ODE_MFMA) {
@@ -142,7 +145,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
   static const CfgOps ops = {
       {NJ_D, NJ_H, NJ_DO, NJ_NH, (NJ_NH > 0 ? NJ_W : 0), NJ_ACT,
        (NJ_MASKED ? NJODE_F_MASKED : 0) | (NJ_CURT ? NJODE_F_INPUT_CURRENT_T : 0) |
-           (NJ_RES ? NJODE_F_RESIDUAL : 0)},
+           (NJ_RES ? NJODE_F_RESIDUAL : 0) | (NJ_RNN ? NJODE_F_USE_RNN : 0)},
       C::P,
       C::ODE_IN,
       C::ENC_IN,
@@ -161,7 +164,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
 
 #if NJ_PART == 1
 template <bool DROP, int ODE> static hipError_t seg_backward_t(const KArgs& a, hipStream_t st) {
-  if constexpr (C::MASKED) {
+  if constexpr (C::MASKED || C::RNN) {
     return hipErrorNotSupported;
   } else if constexpr (ODE == ODE_MFMA) {
     launch_mfma_rows_bwd<C, DROP>(a, st);
@@ -247,6 +250,10 @@ template <bool DROP> static hipError_t lock_bwd_t(const KArgs& a, hipStream_t st
   {
     ProfScope ps("k_enc_dw_rows", st);
     k_enc_dw_rows<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
+  }
+  if constexpr (C::RNN) {
+    ProfScope ps("k_gru_dw_rows", st);
+    k_gru_dw_rows<C><<<a.n_waves, 64, 0, st>>>(a);
   }
   return hipGetLastError();
 }

@@ -15,17 +15,23 @@ constexpr uint32_t NET_ODE = 0, NET_ENC = 1, NET_DEC = 2, NET_DEC_BJ = 3, NET_DE
 constexpr uint32_t TKEY_START = 0xffffffffu;
 
 template <int D_, int H_, int DO_, int NH_, int W_, int ACT_, bool MASKED_, bool CURT_,
-          bool RES_>
+          bool RES_, bool RNN_ = false>
 struct Cfg {
   static constexpr int D = D_, H = H_, DO = DO_, NH = NH_, W = (NH_ > 0 ? W_ : 1), ACT = ACT_;
-  static constexpr bool MASKED = MASKED_, CURT = CURT_, RES = RES_;
+  static constexpr bool MASKED = MASKED_, CURT = CURT_, RES = RES_, RNN = RNN_;
   static constexpr int ODE_IN = D + H + (CURT ? 3 : 2);
   static constexpr int ENC_IN = MASKED ? 2 * D : D;
   using Ode = NetL<ODE_IN, H, NH, W_>;
   using Enc = NetL<ENC_IN, H, NH, W_>;
   using Dec = NetL<H, DO, NH, W_>;
   static constexpr int OFF_ODE = 0, OFF_ENC = Ode::SIZE, OFF_DEC = Ode::SIZE + Enc::SIZE;
-  static constexpr int P = OFF_DEC + Dec::SIZE;
+  // use_rnn: GRU jump (models.py:202-217): nn.GRUCell parameters after the readout, in
+  // state_dict order weight_ih [3H][D], weight_hh [3H][H], bias_ih [3H], bias_hh [3H]
+  static constexpr int OFF_GRU = OFF_DEC + Dec::SIZE;
+  static constexpr int G_WIH = 0, G_WHH = 3 * H * D, G_BIH = G_WHH + 3 * H * H, G_BHH = G_BIH + 3 * H;
+  static constexpr int GRU_SIZE = G_BHH + 3 * H;
+  static constexpr int P = OFF_GRU + (RNN ? GRU_SIZE : 0);
+  static_assert(!(RNN && MASKED), "the GRU jump is not defined for masked models");
   // residual cases of FFNN (models.py:240-259)
   static constexpr int ENC_CASE = !RES ? 0 : (D <= H ? 1 : 2);
   static constexpr int DEC_CASE = !RES ? 0 : (H <= DO ? 1 : 2);
@@ -184,6 +190,34 @@ NJ_DEV void readout(WP Pd, const float (&h)[C::H], float (&th)[C::H], float (&a1
       y[j] += s * (1.0f / mult);
     }
   }
+}
+
+NJ_DEV float sigmoid_f(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// GRU jump (nn.GRUCell on tanh(X_obs), tanh(h)): gates kept for the backward
+template <class C>
+NJ_DEV void gru_jump(cfp Pg, const float (&x)[C::D], const float (&h)[C::H], float (&tx)[C::D],
+                     float (&th)[C::H], float (&r)[C::H], float (&z)[C::H], float (&n)[C::H],
+                     float (&ghn)[C::H], float (&hn)[C::H]) {
+  constexpr int H = C::H, D = C::D;
+  float gi[3 * H], gh[3 * H];
+#pragma unroll
+  for (int i = 0; i < D; ++i) tx[i] = tanh_f(x[i]);
+#pragma unroll
+  for (int i = 0; i < H; ++i) th[i] = tanh_f(h[i]);
+  const cfp P = launder(Pg);
+  dense<D, 3 * H>(P + C::G_WIH, P + C::G_BIH, tx, gi);
+  dense<H, 3 * H>(P + C::G_WHH, P + C::G_BHH, th, gh);
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    r[i] = sigmoid_f(gi[i] + gh[i]);
+    z[i] = sigmoid_f(gi[H + i] + gh[H + i]);
+    ghn[i] = gh[2 * H + i];
+    n[i] = tanh_f(gi[2 * H + i] + r[i] * ghn[i]);
+    hn[i] = (1.0f - z[i]) * n[i] + z[i] * th[i];
+  }
+  pin(hn);
 }
 
 // ODE input vector (models.py:188-199)
@@ -633,8 +667,15 @@ __global__ void __launch_bounds__(64) k_paths_fwd(KArgs a) {
 #pragma unroll
             for (int q = 0; q < C::D; ++q) { xin[q] = x[q]; mask[q] = 1.0f; }
           }
-          mk.draw(a, gid, (uint32_t)k, NET_ENC);
-          encode<C, DROP>(launder(Pe0), xin, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
+          if constexpr (C::RNN) {
+            float gtx[C::D], gth[C::H], gr[C::H], gz[C::H], gn[C::H], gg[C::H], hn[C::H];
+            gru_jump<C>(as_cfp(a.P) + C::OFF_GRU, xin, h, gtx, gth, gr, gz, gn, gg, hn);
+#pragma unroll
+            for (int q = 0; q < C::H; ++q) h[q] = hn[q];
+          } else {
+            mk.draw(a, gid, (uint32_t)k, NET_ENC);
+            encode<C, DROP>(launder(Pe0), xin, mask, ein, a1, a2, mk, a.dc.inv_keep, h);
+          }
           mk.draw(a, gid, (uint32_t)k, NET_DEC);
           readout<C, DROP>(launder(Pd0), h, th, a1, a2, mk, a.dc.inv_keep, y);
           if (LOSS) {

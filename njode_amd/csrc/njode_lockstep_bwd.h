@@ -32,6 +32,29 @@ NJ_DEV void enc_input_grad(const float (&din)[C::D], const float (&ein)[C::ENC_I
   }
 }
 
+// Backward of the GRU jump.  dhn = adjoint of the new state.  Produces the gate gradients
+// (dgi, dgh: the deltas of the two affine maps) and the adjoint of the old state dh.
+template <class C>
+NJ_DEV void gru_gate_grads(const float (&dhn)[C::H], const float (&th)[C::H],
+                           const float (&r)[C::H], const float (&z)[C::H], const float (&n)[C::H],
+                           const float (&ghn)[C::H], float (&dgi)[3 * C::H],
+                           float (&dgh)[3 * C::H], float (&dth)[C::H]) {
+  constexpr int H = C::H;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const float dn = dhn[i] * (1.0f - z[i]);
+    const float dz = dhn[i] * (th[i] - n[i]);
+    dth[i] = dhn[i] * z[i];
+    const float dan = dn * (1.0f - n[i] * n[i]);      // pre-activation of n
+    const float dr = dan * ghn[i];
+    const float dar = dr * r[i] * (1.0f - r[i]);
+    const float daz = dz * z[i] * (1.0f - z[i]);
+    dgi[i] = dar;          dgh[i] = dar;
+    dgi[H + i] = daz;      dgh[H + i] = daz;
+    dgi[2 * H + i] = dan;  dgh[2 * H + i] = dan * r[i];
+  }
+}
+
 // ---- pass 1: adjoint sweep ------------------------------------------------------------------
 template <class C, bool DROP>
 __global__ void __launch_bounds__(64, 1) k_paths_bwd_adj(KArgs a) {
@@ -140,7 +163,8 @@ __global__ void __launch_bounds__(64, 1) k_paths_bwd_adj(KArgs a) {
             for (int q = 0; q < C::D; ++q) dybj[q] += dx[q] * (1.0f - mask[q]);
           }
           store_vec(a.g_ybj + (size_t)r * C::DO, dybj);
-          // y_bj = readout(h_pre): the only path from the state before the jump
+          // y_bj = readout(h_pre): without the GRU the only path from the state before
+          // the jump
           {
             float yy[C::DO];
             mk.draw(a, gid, (uint32_t)k, NET_DEC_BJ);
@@ -148,6 +172,18 @@ __global__ void __launch_bounds__(64, 1) k_paths_bwd_adj(KArgs a) {
             net_bwd_inputs<typename C::Dec, C::ACT, DROP, 0, C::H>(
                 PTd0, dybj, a1, a2, mk.m1, mk.m2, a.dc.inv_keep, a.keep, dinh);
             readout_input_grad<C>(dinh, th, dybj, lam_h);
+          }
+          if constexpr (C::RNN) {
+            // h_new = GRU(tanh(X), tanh(h_pre)): second path into the old state
+            float gtx[C::D], gth[C::H], gr[C::H], gz[C::H], gn[C::H], gg[C::H], hh[C::H];
+            float dgi[3 * C::H], dgh[3 * C::H], dth[C::H], dthw[C::H];
+            gru_jump<C>(as_cfp(a.P) + C::OFF_GRU, x, hp, gtx, gth, gr, gz, gn, gg, hh);
+            gru_gate_grads<C>(lam_hn, gth, gr, gz, gn, gg, dgi, dgh, dth);
+            dense_T_range<C::H, 3 * C::H, 0, C::H>(
+                launder(as_cfp(a.PT) + C::OFF_GRU + C::G_WHH), dgh, dthw);
+#pragma unroll
+            for (int q = 0; q < C::H; ++q)
+              lam_h[q] += (dth[q] + dthw[q]) * (1.0f - gth[q] * gth[q]);
           }
 #pragma unroll
           for (int q = 0; q < C::D; ++q) lam_x[q] = 0.0f;
@@ -247,12 +283,14 @@ __global__ void __launch_bounds__(64, 1) k_enc_dw_rows(KArgs a) {
   NetAcc<NL> g;
   g.zero();
   const cfp Pe0 = as_cfp(a.P) + C::OFF_ENC, PTe0 = as_cfp(a.PT) + C::OFF_ENC;
+  // with the GRU jump the encoder only produces the start states
+  const int first = C::RNN ? a.n_obs : 0;
   const int total = a.n_obs + a.B;
-  const int n_tiles = (total + 63) / 64;
+  const int n_tiles = (total - first + 63) / 64;
   for (int tile = wave; tile < n_tiles; tile += a.n_waves) {
-    const int t0 = tile * 64 + lane;
+    const int t0 = first + tile * 64 + lane;
     const bool valid = t0 < total;
-    const int tid = valid ? t0 : 0;
+    const int tid = valid ? t0 : first;
     const bool is_row = tid < a.n_obs;
     const int r = is_row ? tid : 0;
     const int b = is_row ? a.obs_idx[r] : tid - a.n_obs;
@@ -280,6 +318,41 @@ __global__ void __launch_bounds__(64, 1) k_enc_dw_rows(KArgs a) {
                                     a.keep, din, lane);
   }
   g.flush(a.slab + (size_t)wave * C::P + C::OFF_ENC, lane);
+}
+
+// GRU parameters: outer products of the gate gradients with tanh(X) / tanh(h_pre)
+template <class C>
+__global__ void __launch_bounds__(64, 1) k_gru_dw_rows(KArgs a) {
+  using TI = Tile<3 * C::H, C::D>;
+  using TH = Tile<3 * C::H, C::H>;
+  constexpr int LDSF = TI::LDS_FLOATS > TH::LDS_FLOATS ? TI::LDS_FLOATS : TH::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds_raw[LDSF];
+  lfp lds = (lfp)lds_raw;
+  const int lane = threadIdx.x, wave = blockIdx.x;
+  float acc_i[TI::NACC], acc_h[TH::NACC];
+#pragma unroll
+  for (int q = 0; q < TI::NACC; ++q) acc_i[q] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < TH::NACC; ++q) acc_h[q] = 0.0f;
+  const int n_tiles = (a.n_obs + 63) / 64;
+  for (int tile = wave; tile < n_tiles; tile += a.n_waves) {
+    const int r0 = tile * 64 + lane;
+    const bool valid = r0 < a.n_obs;
+    const int r = valid ? r0 : 0;
+    float x[C::D], hp[C::H], lam[C::H], gtx[C::D], gth[C::H], gr[C::H], gz[C::H], gn[C::H],
+        gg[C::H], hh[C::H], dgi[3 * C::H], dgh[3 * C::H], dth[C::H];
+    load_vec(a.X + (size_t)r * C::D, x);
+    load_vec(a.h_end + (size_t)r * C::H, hp);
+#pragma unroll
+    for (int q = 0; q < C::H; ++q) lam[q] = valid ? a.g_hnew[(size_t)r * C::H + q] : 0.0f;
+    gru_jump<C>(as_cfp(a.P) + C::OFF_GRU, x, hp, gtx, gth, gr, gz, gn, gg, hh);
+    gru_gate_grads<C>(lam, gth, gr, gz, gn, gg, dgi, dgh, dth);
+    TI::update(lds, acc_i, dgi, gtx, lane);
+    TH::update(lds, acc_h, dgh, gth, lane);
+  }
+  float* slab = a.slab + (size_t)wave * C::P + C::OFF_GRU;
+  TI::flush(acc_i, slab + C::G_WIH, slab + C::G_BIH, lane);
+  TH::flush(acc_h, slab + C::G_WHH, slab + C::G_BHH, lane);
 }
 
 }  // namespace njode

@@ -302,18 +302,30 @@ class NJODE(torch.nn.Module):
         return self.weight
 
     # -- flat parameter storage -----------------------------------------------------------
-    def _linears(self):
-        mods = []
+    def _flat_slots(self):
+        """[(parameter or None, slot size, shape)] in the C ABI's order: the Linear
+        layers of the three networks (bias slot always present), then the GRU cell."""
+        slots = []
         for seq in (self.ode_f.f, self.encoder_map.ffnn, self.readout_map.ffnn):
-            mods += [m for m in seq if isinstance(m, torch.nn.Linear)]
-        return mods
+            for m in seq:
+                if isinstance(m, torch.nn.Linear):
+                    slots.append((m.weight, m.weight.numel(), tuple(m.weight.shape)))
+                    slots.append((m.bias, m.out_features, (m.out_features,)))
+        if self.use_rnn:
+            g = self.obs_c.gru_d
+            H3 = 3 * self.hidden_size
+            slots.append((g.weight_ih, g.weight_ih.numel(), tuple(g.weight_ih.shape)))
+            slots.append((g.weight_hh, g.weight_hh.numel(), tuple(g.weight_hh.shape)))
+            slots.append((getattr(g, 'bias_ih', None), H3, (H3,)))
+            slots.append((getattr(g, 'bias_hh', None), H3, (H3,)))
+        return slots
 
     def _ensure_flat(self):
-        """Make every Linear parameter a view of one flat vector laid out as the C
-        ABI expects (state_dict order; bias slots always present)."""
-        lins = self._linears()
-        dev = lins[0].weight.device
-        total = sum(m.weight.numel() + m.out_features for m in lins)
+        """Make every parameter a view of one flat vector laid out as the C ABI expects
+        (state_dict order; bias slots always present)."""
+        slots = self._flat_slots()
+        dev = slots[0][0].device
+        total = sum(n for _, n, _ in slots)
         ok = (self._flat is not None and self._flat.device == dev
               and self._flat.numel() == total)
         if ok:
@@ -326,19 +338,12 @@ class NJODE(torch.nn.Module):
             return
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         slices, params, off = [], [], 0
-        for m in lins:
-            n = m.weight.numel()
-            flat[off:off + n].copy_(m.weight.data.reshape(-1).to(torch.float32))
-            m.weight.data = flat[off:off + n].view(m.weight.shape)
-            slices.append((off, n, tuple(m.weight.shape)))
-            params.append(m.weight)
-            off += n
-            n = m.out_features
-            if m.bias is not None:
-                flat[off:off + n].copy_(m.bias.data.to(torch.float32))
-                m.bias.data = flat[off:off + n]
-                slices.append((off, n, (n,)))
-                params.append(m.bias)
+        for p, n, shape in slots:
+            if p is not None:
+                flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
+                p.data = flat[off:off + n].view(shape)
+                slices.append((off, n, shape))
+                params.append(p)
             off += n
         self._flat, self._param_slices, self._flat_params = flat, slices, params
         self._flat_grad = None
@@ -362,10 +367,9 @@ class NJODE(torch.nn.Module):
     def _get_dims(self):
         if self._dims is not None:
             return self._dims
-        if self.use_rnn:
-            raise NotImplementedError(
-                'use_rnn=True (GRU jump, reference models.py:202-217) is not implemented '
-                'in the HIP path yet')
+        if self.use_rnn and self.masked:
+            raise NotImplementedError('use_rnn with masked data is not defined by the reference '
+                                      '(models.py:353 TODO)')
         if self.solver != 'euler':
             raise ValueError("Unknown solver '{}'.".format(self.solver))
         if None in self._descs or len(set(self._descs)) != 1:
@@ -377,18 +381,19 @@ class NJODE(torch.nn.Module):
         flags = ((_lib.F_MASKED if self.masked else 0)
                  | (_lib.F_INPUT_CURRENT_T if self.input_current_t else 0)
                  | (_lib.F_RESIDUAL if self.residual_enc_dec else 0)
-                 | (_lib.F_LOSS_EASY if self.which_loss == 'easy' else 0))
+                 | (_lib.F_LOSS_EASY if self.which_loss == 'easy' else 0)
+                 | (_lib.F_USE_RNN if self.use_rnn else 0))
         d = _lib.NjodeDims(self.input_size, self.hidden_size, self.output_size, nh, width,
                            act, flags)
         if not _lib.lib().njode_supported(ctypes.byref(d)):
             raise NotImplementedError(
                 'libnjode_hip.so has no gfx950 specialisation for input_size={}, '
                 'hidden_size={}, output_size={}, n_hidden={}, width={}, act={}, masked={}, '
-                'input_current_t={}, residual={}.  Add the shape to CONFIGS in '
+                'input_current_t={}, residual={}, use_rnn={}.  Add the shape to CONFIGS in '
                 'njode_amd/build.py (or NJODE_EXTRA_CONFIGS) and rebuild.  Compiled: {}'
                 .format(self.input_size, self.hidden_size, self.output_size, nh, width,
                         act, self.masked, self.input_current_t, self.residual_enc_dec,
-                        _lib.build_info()))
+                        self.use_rnn, _lib.build_info()))
         self._dims = d
         return d
 

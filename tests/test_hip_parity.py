@@ -14,7 +14,8 @@ from njode_amd import _lib, data_utils, models, stock_model
 
 pytestmark = pytest.mark.gpu
 
-HIP_CASES = [n for n in all_model_cases() if n != 'g6_use_rnn']
+HIP_CASES = all_model_cases()
+# gradient cases of the segment plan and (use_rnn: sequential jump) of the lockstep plan
 SEG_GRAD_CASES = [n for n in HIP_CASES if not n.startswith(('g1_', 'g5_'))]
 
 
@@ -203,13 +204,6 @@ def test_lockstep_backward_matches_reference_on_unmasked_models(name):
     got = grads_by_name(m)
     for k, ref in g.group('grad').items():
         assert rel_l2(got[k], ref) < GRAD_REL_L2, (k, rel_l2(got[k], ref))
-
-
-def test_use_rnn_fails_loudly():
-    g = Golden('g6_use_rnn')
-    m = hip_model(g.cfg, g.state_dict())
-    with pytest.raises(NotImplementedError, match='use_rnn'):
-        hip_forward(m, g.batch(), g.delta_t, g.T)
 
 
 def test_unsupported_shape_fails_loudly():

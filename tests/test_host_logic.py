@@ -117,6 +117,20 @@ def test_bias_free_model_keeps_zero_bias_slots():
     assert float(flat[650:700].abs().sum()) == 0.0      # ode_f.f.0 bias slot
 
 
+def test_gru_parameters_extend_the_flat_vector():
+    g = Golden('g6_use_rnn')
+    m = models.NJODE(**g.cfg)
+    assert list(m.state_dict().keys()) == list(g.state_dict().keys())
+    m.load_state_dict(g.state_dict())
+    flat = m.flat_parameters()
+    assert flat.numel() == 10071 + 3 * 10 * (1 + 10 + 2)
+    sd, off = g.state_dict(), 0
+    for k in sd:
+        n = sd[k].numel()
+        assert torch.equal(flat[off:off + n], sd[k].reshape(-1)), k
+        off += n
+
+
 def test_residual_size_errors_match_reference():
     nn = ((50, 'tanh'), (50, 'tanh'))
     with pytest.raises(ValueError, match='output_size needs to be multiple of input_size'):
