@@ -111,6 +111,25 @@ def cpu_baseline(meta_dt, T, seconds_budget=28.0):
             'host_cpu_count': os.cpu_count()}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, tools/summarize_pmc.py; KiB units).  The
+    gfx950 x2 FETCH_SIZE correction applies to wide coalesced streams; this kernel's
+    accesses are 4-byte, so the raw counters are reported (MI355X_MICROARCH.md, HBM)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*final_pmc_summary.json')))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f).get(kernel, {})
+        if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            return int((d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -221,7 +240,8 @@ def main():
                 out['roofline'] = {
                     'bound': 'mfma', 'kernel': dom, 'achieved': round(tf_k, 3),
                     'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                    'frac': round(tf_k / FP32_MFMA_PEAK_TF, 5), 'traffic': None,
+                    'frac': round(tf_k / FP32_MFMA_PEAK_TF, 5),
+                    'traffic': measured_traffic(dom),
                     'kernel_ms': round(dom_ms, 5),
                     'algorithmic_flops': int(2 * macs * euler_steps),
                     'note': 'f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak = f32 vector peak; '

@@ -76,6 +76,10 @@ def _run(cmd):
 
 def build(force=False, jobs=None, verbose=True):
     cfgs = all_configs()
+    only = os.environ.get('NJODE_CONFIGS_ONLY', '').strip()   # e.g. "0": quick kernel experiments
+    if only:
+        keep = {int(x) for x in only.split(',')}
+        cfgs = [c for i, c in enumerate(cfgs) if i in keep]
     os.makedirs(OBJ, exist_ok=True)
     inc = ''.join('NJ_CFG({})\n'.format(i) for i in range(len(cfgs)))
     inc_path = os.path.join(CSRC, '_generated_cfgs.inc')
