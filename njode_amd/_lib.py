@@ -21,7 +21,11 @@ C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD = 0x1, 0x2, 0x4, 0x8
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
            'njode_forward_f32', 'njode_backward_f32', 'njode_adam_step_f32',
            'njode_last_error', 'njode_build_info', 'njode_profile_enable',
-           'njode_profile_read')
+           'njode_profile_read',
+           # include/njode_producer.h
+           'njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
+           'njode_collate_count', 'njode_collate_fill')
+SDE_MODELS = {'BlackScholes': 0, 'OrnsteinUhlenbeck': 1, 'Heston': 2}
 
 
 class NjodeDims(C.Structure):
@@ -42,6 +46,14 @@ class NjodeBatch(C.Structure):
                 ('start_X', C.c_void_p), ('X', C.c_void_p), ('M', C.c_void_p),
                 ('obs_idx', C.c_void_p), ('n_obs_ot', C.c_void_p),
                 ('loss_batch_size', C.c_float), ('path_id_offset', C.c_int64)]
+
+
+class NjodeSde(C.Structure):
+    _fields_ = [('model', C.c_int32), ('n_paths', C.c_int32), ('dim', C.c_int32),
+                ('n_steps', C.c_int32), ('has_sine', C.c_int32), ('reserved', C.c_int32),
+                ('drift', C.c_double), ('volatility', C.c_double), ('mean', C.c_double),
+                ('speed', C.c_double), ('correlation', C.c_double), ('S0', C.c_double),
+                ('maturity', C.c_double), ('sine_coeff', C.c_double)]
 
 
 class NjodeError(RuntimeError):
@@ -93,6 +105,16 @@ def lib():
     L.njode_profile_enable.restype = C.c_int
     L.njode_profile_read.argtypes = [C.c_char_p, sz]
     L.njode_profile_read.restype = C.c_int
+    f64 = C.c_double
+    L.njode_philox4x32_10.argtypes = [i32, vp, vp, vp, vp]
+    L.njode_generate_paths.argtypes = [C.POINTER(NjodeSde), u64, vp, vp, vp]
+    L.njode_sample_observations.argtypes = [i32, i32, f64, u64, vp, vp, vp, vp]
+    L.njode_collate_count.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp, vp]
+    L.njode_collate_fill.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp,
+                                     C.POINTER(C.c_int32), i32, vp, vp, vp, vp]
+    for name in ('njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
+                 'njode_collate_count', 'njode_collate_fill'):
+        getattr(L, name).restype = C.c_int
     _lib = L
     return L
 

@@ -89,13 +89,17 @@ def build(force=False, jobs=None, verbose=True):
     cc = _hipcc()
     common = [cc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c']
     hdr = os.path.join(os.path.dirname(HERE), 'include', 'njode_hip.h')
+    hdr_prod = os.path.join(os.path.dirname(HERE), 'include', 'njode_producer.h')
     kernel_deps = [os.path.join(CSRC, n) for n in
                    ('njode_cfg.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
-                    'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h')] + [hdr]
+                    'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
+                    'njode_mfma_lockstep.h')] + [hdr]
     api_deps = [os.path.join(CSRC, n) for n in
                 ('njode_api.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
                  'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
-                 '_generated_cfgs.inc')] + [hdr]
+                 'njode_mfma_lockstep.h', 'njode_error.h', '_generated_cfgs.inc')] + [hdr]
+    prod_deps = [os.path.join(CSRC, n) for n in ('njode_producer.hip', 'njode_error.h')] + [
+        hdr, hdr_prod]
     tasks = []   # (object, command, digest)
     for i, (d, h, do, nh, w, act, masked, curt, res, rnn) in enumerate(cfgs):
         for part in range(4):
@@ -110,6 +114,15 @@ def build(force=False, jobs=None, verbose=True):
     api_obj = os.path.join(OBJ, 'api.o')
     cmd = common + [os.path.join(CSRC, 'njode_api.hip'), '-o', api_obj]
     tasks.append((api_obj, cmd, _digest(api_deps, ' '.join(cmd))))
+    # the batch producer spells out the reference's float64 expression trees: no contraction
+    prod_obj = os.path.join(OBJ, 'producer.o')
+    cmd = common + ['-ffp-contract=off', os.path.join(CSRC, 'njode_producer.hip'), '-o', prod_obj]
+    tasks.append((prod_obj, cmd, _digest(prod_deps, ' '.join(cmd))))
+    if os.environ.get('NJODE_RESTAMP'):   # maintainer aid: adopt the objects on disk as current
+        for t in tasks:
+            if os.path.exists(t[0]):
+                with open(t[0] + '.stamp', 'w') as f:
+                    f.write(t[2])
 
     def stale(t):
         stamp = t[0] + '.stamp'

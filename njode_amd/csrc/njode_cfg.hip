@@ -24,6 +24,9 @@ hipError_t NJ_CAT(njode_seg_backward_, NJ_ID)(const KArgs& a, bool drop, int ode
 constexpr bool HAS_MFMA = C::NH == 2 && !C::MASKED && !C::RNN && C::DO <= 16 && C::W < 64;
 // the lockstep forward on the matrix cores also covers masked shapes
 constexpr bool HAS_MFMA_LOCK = C::NH == 2 && !C::RNN && C::W < 64 && C::H <= 64 && C::DO <= 64;
+// ... and so does its adjoint sweep, unless the encoder's identity path folds units
+constexpr bool HAS_MFMA_SWEEP =
+    HAS_MFMA_LOCK && (!C::MASKED || C::ENC_CASE == 0 || (C::ENC_CASE == 1 && C::D == C::H));
 template <bool ON, class CC> struct FragSize {
   static constexpr int ode = 0, enc = 0, dec = 0;
 };
@@ -85,7 +88,7 @@ template <class CC, bool DROP, bool TAIL> static void launch_mfma_fwd(const KArg
 
 hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool path, bool loss, int ode,
                                              hipStream_t st);
-hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
+hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st);
 
 #if NJ_PART == 0
 template <bool DROP, bool TAIL, int ODE> static void launch_ode_fwd(const KArgs& a, hipStream_t st) {
@@ -157,7 +160,8 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       NJ_CAT(njode_lock_backward_, NJ_ID),
       MF_FLOATS,
       FS::ode,
-      FS::ode + FS::enc};
+      FS::ode + FS::enc,
+      HAS_MFMA_SWEEP ? 1 : 0};
   return &ops;
 }
 #endif
@@ -234,31 +238,72 @@ hipError_t NJ_CAT(njode_lock_forward_, NJ_ID)(const KArgs& a, bool drop, bool pa
 #endif
 
 #if NJ_PART == 3
-template <bool DROP> static hipError_t lock_bwd_t(const KArgs& a, hipStream_t st) {
-  {
-    ProfScope ps("k_paths_bwd_adj", st);
-    k_paths_bwd_adj<C, DROP><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+template <class CC, bool DROP> static void lock_bwd_mfma(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA_SWEEP) {
+    using ES = typename EncS<CC>::type;
+    using DS = typename DecS<CC>::type;
+    k_pack_frags<CC><<<cdiv(MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag);
+    k_pack_net<typename CC::Enc, ES><<<cdiv(ES::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_ENC,
+                                                                             a.frag_enc);
+    k_pack_net<typename CC::Dec, DS><<<cdiv(DS::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_DEC,
+                                                                             a.frag_dec);
+    {
+      ProfScope ps("k_paths_bwd_adj_mfma", st);
+      k_paths_bwd_adj_mfma<CC, DROP><<<cdiv(a.B, 16), 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_ode_dw_pairs_mfma", st);
+      k_ode_dw_pairs_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_dec_dw_rows_mfma", st);
+      k_dec_dw_rows_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_enc_dw_rows_mfma", st);
+      k_enc_dw_rows_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
+    }
   }
-  {
-    ProfScope ps("k_ode_dw_pairs", st);
-    k_ode_dw_pairs<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
-  }
-  {
-    ProfScope ps("k_dec_dw_rows", st);
-    k_dec_dw_rows<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
-  }
-  {
-    ProfScope ps("k_enc_dw_rows", st);
-    k_enc_dw_rows<C, DROP><<<a.n_waves, 64, 0, st>>>(a);
-  }
-  if constexpr (C::RNN) {
-    ProfScope ps("k_gru_dw_rows", st);
-    k_gru_dw_rows<C><<<a.n_waves, 64, 0, st>>>(a);
-  }
-  return hipGetLastError();
 }
-hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
-  return drop ? lock_bwd_t<true>(a, st) : lock_bwd_t<false>(a, st);
+// The one-lane-per-path sweep holds a path's whole state in registers: fine for the small
+// unmasked shapes, but the 41-dimensional masked ones spill thousands of registers, so
+// masked shapes are only differentiated on the matrix cores.
+template <class CC, bool DROP> static hipError_t lock_bwd_valu(const KArgs& a, hipStream_t st) {
+  if constexpr (CC::MASKED) {
+    return hipErrorNotSupported;
+  } else {
+    {
+      ProfScope ps("k_paths_bwd_adj", st);
+      k_paths_bwd_adj<CC, DROP><<<cdiv(a.B, 64), 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_ode_dw_pairs", st);
+      k_ode_dw_pairs<CC, DROP><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_dec_dw_rows", st);
+      k_dec_dw_rows<CC, DROP><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    {
+      ProfScope ps("k_enc_dw_rows", st);
+      k_enc_dw_rows<CC, DROP><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    if constexpr (CC::RNN) {
+      ProfScope ps("k_gru_dw_rows", st);
+      k_gru_dw_rows<CC><<<a.n_waves, 64, 0, st>>>(a);
+    }
+    return hipGetLastError();
+  }
+}
+template <bool DROP> static hipError_t lock_bwd_t(const KArgs& a, int ode, hipStream_t st) {
+  if (ode == ODE_MFMA && HAS_MFMA_SWEEP) {
+    lock_bwd_mfma<C, DROP>(a, st);
+    return hipGetLastError();
+  }
+  return lock_bwd_valu<C, DROP>(a, st);
+}
+hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st) {
+  return drop ? lock_bwd_t<true>(a, ode, st) : lock_bwd_t<false>(a, ode, st);
 }
 #endif
 

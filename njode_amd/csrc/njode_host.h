@@ -26,9 +26,11 @@ struct CfgOps {
   // lockstep plan
   // ode: ODE_MFMA runs the matrix-core lockstep kernel where the shape has one
   hipError_t (*lock_forward)(const KArgs&, bool drop, bool path, bool loss, int ode, hipStream_t);
-  hipError_t (*lock_backward)(const KArgs&, bool drop, hipStream_t);
+  // ode: the implementation the saving forward ran (decides the dropout keying)
+  hipError_t (*lock_backward)(const KArgs&, bool drop, int ode, hipStream_t);
   int frag_floats;  // size of the fragment buffer (0: no MFMA kernels for this shape)
   int frag_enc_off, frag_dec_off;  // offsets of the encoder / readout fragments in it
+  int lock_sweep_mfma;  // the lockstep backward has a matrix-core adjoint sweep
 };
 
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events

@@ -111,7 +111,7 @@ struct KArgs {
   float weight;
   int loss_easy;
   int want_path, want_loss;  // lockstep plan: return_path / get_loss (wave-uniform)
-  int save_traj;             // segment plan: checkpoint states for the backward pass
+  int save_traj;             // checkpoint states for the backward pass
   DropCtx dc;
   float keep;
 };

@@ -39,8 +39,10 @@ template <class C> struct MF {
   static constexpr int NFWD = F3 + MTH * Q1;
   static constexpr int B3 = NFWD;               // W3^T [MT1][QH]
   static constexpr int B2 = B3 + MT1 * QH;      // W2^T [MT1][QW]
-  static constexpr int B1 = B2 + MT1 * QW;      // W1^T [MTH][QW]  (rows = h inputs)
-  static constexpr int NALL = B1 + MTH * QW;
+  // W1^T rows: the h inputs; masked models also need d/d x (the prediction is fed back)
+  static constexpr int MTB1 = C::MASKED ? (H + D + 15) / 16 : MTH;
+  static constexpr int B1 = B2 + MT1 * QW;      // W1^T [MTB1][QW]
+  static constexpr int NALL = B1 + MTB1 * QW;
   // in0 unit order: [h (H), x (D), tau, tdiff, (tau + tdiff), 1]; reference column of unit u
   static constexpr int col0(int u) { return u < H ? D + u : (u < H + D ? u - H : u); }
   static_assert(C::NH == 2, "MFMA ODE kernels are written for two hidden layers");

@@ -181,14 +181,15 @@ NJ_DEV void mnet_fwd(FP& F, const float (&b0)[S::Q0], float (&a1)[S::Q1],
 
 // backward of one evaluation: dW into G, optionally d/d inputs (pre-tanh factor not
 // applied) in din.  a1 / a2 / b0 as produced by mnet_fwd.  Wave-uniform control flow.
-template <class S, int ACT, bool DROP, bool DIN, class FP>
+template <class S, int ACT, bool DROP, bool DIN, class FP, int ROWS = IMG_ROWS>
 NJ_DEV void mnet_bwd(FP& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
                      const float (&dout)[S::QO], const float (&b0)[S::Q0],
                      const float (&a1)[S::Q1], const float (&a2)[S::Q1], uint32_t k1,
                      uint32_t k2, float inv_keep, float keepf, f32x4 (&din)[DIN ? S::MTI : 1],
                      int g, int c) {
-  static_assert(S::W + 1 <= IMG_ROWS && S::IN + 1 <= IMG_ROWS && S::OUT <= IMG_ROWS,
-                "dW staging images hold at most IMG_ROWS units");
+  static_assert(16 * S::NT1 <= ROWS && 16 * S::NT0 <= ROWS && 16 * S::MTO <= ROWS &&
+                    16 * S::MT1 <= ROWS,
+                "dW staging images hold at most ROWS units");
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[S::MT1];
   Bf.begin();

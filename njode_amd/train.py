@@ -26,7 +26,7 @@ import time
 import numpy as np
 import torch
 
-from . import data_utils, models, parallel, stock_model
+from . import data_utils, device_data, models, parallel, stock_model
 
 METR_COLUMNS = ['epoch', 'train_time', 'eval_time', 'train_loss', 'eval_loss',
                 'optimal_eval_loss']
@@ -62,10 +62,14 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
           enc_nn=((50, 'tanh'), (50, 'tanh')), use_rnn=False, solver='euler', weight=0.5,
           weight_decay=1., test_size=0.2, seed=398, device='cuda', fused=True,
           evaluate=False, shuffle_seed=0, log=print, max_steps_per_epoch=None,
-          **options):
+          device_collate=False, **options):
     """Train on an in-memory dataset ``(stock_paths, observed_dates, nb_obs)`` with
     ``metadata`` as returned by ``data_utils.create_dataset``.  Returns
-    ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch."""
+    ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch.
+
+    ``device_collate=True`` uploads the dataset once and builds every training batch with the
+    GPU collate (``device_data.DeviceDataset``): same batches bit for bit, without the
+    per-step host collate and host-to-device copies."""
     stock_paths, observed_dates, nb_obs = dataset_arrays
     delta_t, T = metadata['dt'], metadata['maturity']
     input_size = output_size = metadata['dimension']
@@ -98,6 +102,8 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
     val_d = _device_batch(val, device)
     val_d['n_obs_ot'] = val['n_obs_ot'].to(device, torch.int32)   # eval uses the dataset's count
 
+    dev_ds = device_data.DeviceDataset.from_arrays(stock_paths, observed_dates, nb_obs, metadata,
+                                                   device) if device_collate else None
     metrics = []
     while model.epoch <= epochs:
         t0 = time.time()
@@ -112,9 +118,12 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             lo, hi = parallel.shard_range(len(idx), world, rank)
             parallel.configure_model(model, len(idx), lo)
             mine = idx[lo:hi]
-            b = data_utils.collate_arrays(stock_paths[mine], observed_dates[mine], nb_obs[mine],
-                                          delta_t, funcs)
-            d = _device_batch(b, device)
+            if dev_ds is not None:
+                d = dev_ds.collate(mine, func_names=functions or ())
+            else:
+                b = data_utils.collate_arrays(stock_paths[mine], observed_dates[mine],
+                                              nb_obs[mine], delta_t, funcs)
+                d = _device_batch(b, device)
             args = (d['times'], d['time_ptr'], d['X'], d['obs_idx'], delta_t, T, d['start_X'],
                     d['n_obs_ot'])
             optimizer.zero_grad()

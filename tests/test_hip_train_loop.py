@@ -65,3 +65,15 @@ def test_loop_matches_oracle_loop_for_a_few_steps():
     flat_ref = torch.cat([params[k].detach().reshape(-1) for k in sd])
     np.testing.assert_allclose(model.flat_parameters().cpu().numpy(), flat_ref.numpy(),
                                atol=5e-5, rtol=1e-3)
+
+
+def test_device_collated_loop_is_bit_identical():
+    """The GPU batch producer's collate feeds the same batches as the host collate, so the
+    whole training trajectory (dropout on) is identical."""
+    data, meta = _dataset(n=400)
+    m1, met1 = train.train(data, meta, epochs=2, batch_size=64, dropout_rate=0.1,
+                           log=lambda s: None)
+    m2, met2 = train.train(data, meta, epochs=2, batch_size=64, dropout_rate=0.1,
+                           device_collate=True, log=lambda s: None)
+    assert torch.equal(m1.flat_parameters(), m2.flat_parameters())
+    assert met1[1][3] == met2[1][3] and met1[1][4] == met2[1][4]

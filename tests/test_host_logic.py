@@ -162,9 +162,10 @@ def test_checkpoint_roundtrip(tmp_path):
 
 
 def test_library_loads_and_exports_declared_symbols():
-    """Every function declared in include/njode_hip.h is exported by the built
-    library (built by __graft_entry__.build(); no GPU needed to load it)."""
-    header = open(os.path.join(REPO, 'include', 'njode_hip.h')).read()
+    """Every function declared in include/*.h is exported by the built library (built by
+    __graft_entry__.build(); no GPU needed to load it)."""
+    header = ''.join(open(os.path.join(REPO, 'include', n)).read()
+                     for n in sorted(os.listdir(os.path.join(REPO, 'include'))))
     declared = set(re.findall(r'\b(njode_[a-z0-9_]+)\s*\(', header))
     assert declared == set(_lib.EXPORTS)
     if not os.path.exists(_lib.LIB_PATH):
