@@ -18,6 +18,7 @@ Launch:  python bench.py --gpus 1 --steps K --warmup W
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import copy
 import json
 import os
@@ -161,7 +162,8 @@ def main():
     b, meta = make_batch(B, seed=rank)
     dt, T = meta['dt'], meta['maturity']
     torch.manual_seed(0)                       # identical init on every rank
-    model = models.NJODE(**model_cfg(args.dropout)).to(dev).train()
+    with contextlib.redirect_stdout(sys.stderr):   # the ctor prints like the reference's does
+        model = models.NJODE(**model_cfg(args.dropout)).to(dev).train()
     model.dp_global_batch = B * world
     model.dp_path_offset = B * rank
     opt = models.FusedAdam(model, lr=1e-3, weight_decay=0.0005, distributed=distributed)
@@ -259,8 +261,9 @@ def main():
                                  'useful_flops_per_step': int(flops),
                                  'note': 'whole step incl. plan, reductions, Adam, launches'}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(dt, T)
-        print(json.dumps(out))
+            with contextlib.redirect_stdout(sys.stderr):
+                out['cpu_baseline'] = cpu_baseline(dt, T)
+        print(json.dumps(out), flush=True)   # the ONE line on stdout
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
