@@ -150,11 +150,19 @@ def main():
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
     if args.gpus > 1 and not distributed:
         raise SystemExit('launch N > 1 with torch.distributed.run (one rank per GPU)')
+    # NJODE_BENCH_SHARE_GPU=1 (self-test of the N > 1 code path on a one-GPU box): ranks share
+    # device 0 and the collective runs over gloo; never set by the driver
+    share = os.environ.get('NJODE_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if distributed:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', device_id=dev)
+        if share:
+            torch.distributed.init_process_group('gloo')
+        else:
+            torch.distributed.init_process_group('nccl', device_id=dev)
 
     from njode_amd import _lib, models
 
@@ -234,7 +242,7 @@ def main():
             #   forward : (IN0+1) W + (W+1) W + (W+1) H                      = 3 760 MAC
             #   backward: recompute L1+L2 3 250 + transposed products 3 500
             #             + weight-gradient outer products 3 760             = 10 510 MAC
-            macs = {'k_ode_bwd_mfma': 10510, 'k_ode_bwd_items': 10510 + 510,
+            macs = {'k_ode_bwd_mixed': 10510, 'k_ode_bwd_mfma': 10510, 'k_ode_bwd_items': 10510 + 510,
                     'k_ode_fwd_mfma': 3760, 'k_ode_fwd_items': 3760}.get(dom)
             bytes_ = euler_steps * H * 4 + n_obs * (2 * H * 4 + 32)
             if macs is not None:

@@ -3,6 +3,8 @@
 // 1 segment backward, 2 lockstep forward, 3 lockstep backward) with
 //   -DNJ_ID=.. -DNJ_D=.. -DNJ_H=.. -DNJ_DO=.. -DNJ_NH=.. -DNJ_W=.. -DNJ_ACT=..
 //   -DNJ_MASKED=.. -DNJ_CURT=.. -DNJ_RES=.. -DNJ_PART=..
+#include <cstdlib>
+
 #include "njode_host.h"
 
 #define NJ_CAT_(a, b) a##b
@@ -27,6 +29,7 @@ constexpr bool HAS_MFMA_LOCK = C::NH == 2 && !C::RNN && C::W < 64 && C::H <= 64 
 // ... and so does its adjoint sweep, unless the encoder's identity path folds units
 constexpr bool HAS_MFMA_SWEEP =
     HAS_MFMA_LOCK && (!C::MASKED || C::ENC_CASE == 0 || (C::ENC_CASE == 1 && C::D == C::H));
+constexpr bool HAS_SPLIT = HAS_MFMA && SplitOk<C>::value;
 template <bool ON, class CC> struct FragSize {
   static constexpr int ode = 0, enc = 0, dec = 0;
 };
@@ -63,25 +66,44 @@ template <class CC, bool DROP> static void launch_mfma_jump(const KArgs& a, hipS
     k_jump_rows_mfma<CC, DROP><<<n_tiles < 2048 ? n_tiles : 2048, 64, 0, st>>>(a);
   }
 }
-template <class CC, bool DROP> static void launch_mfma_rows_bwd(const KArgs& a, hipStream_t st) {
+template <class CC, bool DROP> static void launch_ode_bwd_mfma(const KArgs& a, bool split, hipStream_t st) {
+  if constexpr (HAS_MFMA) {
+    if constexpr (HAS_SPLIT) {
+      if (split) {
+        ProfScope ps("k_ode_bwd_mixed", st);
+        k_ode_bwd_mixed<CC, DROP><<<a.n_blocks_bwd, 256, 0, st>>>(a);
+        return;
+      }
+    }
+    ProfScope ps("k_ode_bwd_mfma", st);
+    k_ode_bwd_mfma<CC, DROP><<<a.n_waves_ode / 4, 256, 0, st>>>(a);
+  }
+}
+template <class CC, bool DROP>
+static void launch_mfma_rows_bwd(const KArgs& a, bool split, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     {
       ProfScope ps("k_jump_rows_bwd_mfma", st);
       k_jump_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
     }
-    {
-      ProfScope ps("k_ode_bwd_mfma", st);
-      k_ode_bwd_mfma<CC, DROP><<<a.n_waves_ode / 4, 256, 0, st>>>(a);
-    }
+    launch_ode_bwd_mfma<CC, DROP>(a, split, st);
     {
       ProfScope ps("k_encode_rows_bwd_mfma", st);
       k_encode_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
     }
   }
 }
-template <class CC, bool DROP, bool TAIL> static void launch_mfma_fwd(const KArgs& a, hipStream_t st) {
+template <class CC, bool DROP, bool TAIL>
+static void launch_mfma_fwd(const KArgs& a, bool split, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     const int n_tiles = cdiv(TAIL ? a.B : a.n_obs, 16);
+    if constexpr (HAS_SPLIT) {
+      if (split) {
+        if constexpr (TAIL) k_ode_fwd_split<CC, DROP, true><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, st>>>(a);
+        else k_ode_fwd_mixed<CC, DROP><<<a.n_blocks_fwd, 256, 0, st>>>(a);
+        return;
+      }
+    }
     k_ode_fwd_mfma<CC, DROP, TAIL><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
   }
 }
@@ -94,7 +116,7 @@ hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, int od
 template <bool DROP, bool TAIL, int ODE> static void launch_ode_fwd(const KArgs& a, hipStream_t st) {
   const int n_items = TAIL ? a.B : a.n_obs;
   if constexpr (ODE == ODE_MFMA) {
-    launch_mfma_fwd<C, DROP, TAIL>(a, st);
+    launch_mfma_fwd<C, DROP, TAIL>(a, a.ode_split != 0, st);
   } else {
     constexpr bool WLDS = ODE == ODE_VALU_LDS;
     constexpr int NT = WLDS ? 256 : 64;
@@ -161,7 +183,8 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       MF_FLOATS,
       FS::ode,
       FS::ode + FS::enc,
-      HAS_MFMA_SWEEP ? 1 : 0};
+      HAS_MFMA_SWEEP ? 1 : 0,
+      HAS_SPLIT ? 1 : 0};
   return &ops;
 }
 #endif
@@ -171,7 +194,7 @@ template <bool DROP, int ODE> static hipError_t seg_backward_t(const KArgs& a, h
   if constexpr (C::MASKED || C::RNN) {
     return hipErrorNotSupported;
   } else if constexpr (ODE == ODE_MFMA) {
-    launch_mfma_rows_bwd<C, DROP>(a, st);
+    launch_mfma_rows_bwd<C, DROP>(a, a.ode_split != 0, st);
     return hipGetLastError();
   } else {
     {

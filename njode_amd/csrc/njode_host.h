@@ -5,13 +5,16 @@
 #include "../../include/njode_hip.h"
 #include "njode_lockstep_bwd.h"
 #include "njode_mfma_lockstep.h"
+#include "njode_mfma_split.h"
 
 namespace njode {
 
 constexpr int MAX_WAVES = 2048;
 // ODE-evolve implementations: matrix cores (default where compiled), VALU with weights
 // through the scalar cache, VALU with LDS-staged weights
-constexpr int ODE_MFMA = 0, ODE_VALU = 1, ODE_VALU_LDS = 2;  // persistent gradient kernels: 256 CUs x 8 waves
+constexpr int ODE_MFMA = 0, ODE_VALU = 1, ODE_VALU_LDS = 2;
+// (NJODE_ODE=mfma1 keeps ODE_MFMA but with one wave per tile, njode_mfma.h, where the default
+// picks the four-waves-per-tile kernels of njode_mfma_split.h: A/B baseline)  // persistent gradient kernels: 256 CUs x 8 waves
 
 struct CfgOps {
   NjodeDims dims;
@@ -31,6 +34,7 @@ struct CfgOps {
   int frag_floats;  // size of the fragment buffer (0: no MFMA kernels for this shape)
   int frag_enc_off, frag_dec_off;  // offsets of the encoder / readout fragments in it
   int lock_sweep_mfma;  // the lockstep backward has a matrix-core adjoint sweep
+  int ode_split;        // ODE_MFMA runs the four-waves-per-tile ODE kernels (one slab row per block)
 };
 
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events

@@ -112,6 +112,10 @@ struct KArgs {
   int loss_easy;
   int want_path, want_loss;  // lockstep plan: return_path / get_loss (wave-uniform)
   int save_traj;             // checkpoint states for the backward pass
+  int ode_split;             // segment plan: ODE kernels with four waves per tile (njode_mfma_split.h)
+  // ... mixed kernels: the first n_split_* blocks run the longest tiles four waves per tile,
+  // the other blocks one wave per tile (njode_mfma_split.h); grid sizes
+  int n_split_blocks, n_blocks_bwd, n_split_fwd, n_blocks_fwd;
   DropCtx dc;
   float keep;
 };

@@ -155,10 +155,11 @@ NJ_DEV void hidden_from_acc(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q
 }
 
 // B (MFMA): Euler evolve of every item; 16 items per wave, persistent over tiles.
+// worker `wave` of `n_waves` walks the tiles [tile0, tile1) in snake order
 template <class C, bool DROP, bool TAIL>
-__global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
+NJ_DEV void ode_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int tile0, int tile1) {
   using M = MF<C>;
-  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int g = lane >> 4, c = lane & 15;
   float A1[M::MT1][M::Q0], A2[M::MT1][M::Q1], A3[M::MTH][M::Q1];
 #pragma unroll
   for (int mt = 0; mt < M::MT1; ++mt) {
@@ -174,11 +175,12 @@ __global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
 
   const bool SAVE = !TAIL && a.save_traj != 0;
   const int n_items = TAIL ? a.B : a.n_obs;
-  const int n_tiles = (n_items + 15) / 16;
+  const int n_tiles = tile1 - tile0;
   float* const trash = a.trash + lane * C::H;
-  for (int round = 0; round * (int)gridDim.x < n_tiles; ++round) {
-    const int tile = snake_tile(round, blockIdx.x, gridDim.x);
-    if (tile >= n_tiles) continue;
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
     const int j = tile * 16 + c;
     const bool valid = j < n_items;
     Item<C> it;
@@ -267,6 +269,11 @@ __global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
     }
   }
 }
+template <class C, bool DROP, bool TAIL>
+__global__ void __launch_bounds__(64) k_ode_fwd_mfma(KArgs a) {
+  const int n_items = TAIL ? a.B : a.n_obs;
+  ode_fwd_single<C, DROP, TAIL>(a, threadIdx.x, blockIdx.x, gridDim.x, 0, (n_items + 15) / 16);
+}
 
 
 // ---- backward ----------------------------------------------------------------------------
@@ -348,18 +355,22 @@ template <class C> struct OdeLdsFrags {
   NJ_DEV float b1(int mt, int q) const { return cur[(M::B1 - SKIP + mt * M::QW + q) * 64]; }
 };
 
+template <class C> struct OdeBwdSingleLds {
+  static constexpr int FLOATS = 4 * 2 * IMG_FLOATS + OdeLdsFrags<C>::NVEC * 64;
+};
+// one 256-thread block = 4 independent workers; worker `wave` of `n_waves` walks the tiles
+// [tile0, tile1) in snake order and flushes its gradient tiles into slab row `slab_row`
 template <class C, bool DROP>
-__global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
+NJ_DEV void ode_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
+                           int slab_row) {
   using M = MF<C>;
   using NL = typename C::Ode;
   using FR = OdeLdsFrags<C>;
   constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
   constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
-  __shared__ __attribute__((aligned(16))) float lds_raw[4 * 2 * IMG_FLOATS + FR::NVEC * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
-  lfp img_d = (lfp)lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
-  lfp fimg = (lfp)lds_raw + 4 * 2 * IMG_FLOATS;
+  lfp img_d = lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
+  lfp fimg = lds_raw + 4 * 2 * IMG_FLOATS;
   FR::stage(fimg, a.frag, threadIdx.x, 256);
   // image rows that no vector writes must be finite (they meet zero deltas / feed
   // accumulator entries that are never flushed)
@@ -382,10 +393,11 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
     for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
   }
   float* const trash = a.trash + threadIdx.x * C::H;
-  const int n_tiles = (a.n_obs + 15) / 16;
+  const int n_tiles = tile1 - tile0;
   for (int round = 0; round * n_waves < n_tiles; ++round) {
-    const int tile = snake_tile(round, wave, n_waves);
-    if (tile >= n_tiles) continue;
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
     Item<C> it;
@@ -517,7 +529,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
   }
 
   // ---- flush the register tiles into this wave's slab (parameter layout)
-  float* slab = a.slab + (size_t)wave * C::P + C::OFF_ODE;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
   float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
         *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
 #pragma unroll
@@ -554,6 +566,12 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
         }
       }
     }
+}
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdSingleLds<C>::FLOATS];
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, gridDim.x * 4, 0, (a.n_obs + 15) / 16, wave);
 }
 
 }  // namespace njode

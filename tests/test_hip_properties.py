@@ -159,3 +159,37 @@ def test_dropout_gradient_matches_finite_differences():
     fd = (vals[0] - vals[1]) / (2 * eps)
     an = float((g * v).sum())
     assert fd == pytest.approx(an, rel=3e-2, abs=1e-4)
+
+
+_ROLE_SNIPPET = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {repo!r})
+from hip_util import bs_batch, demo_cfg, hip_model
+b, meta = bs_batch(20000, seed=0)
+torch.manual_seed(0)
+m = hip_model(demo_cfg(dropout=0.1)).train()
+m._step_counter = 11
+_, loss = m.loss_and_grad(b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(),
+                          meta['dt'], meta['maturity'], b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+np.save({out!r}, np.concatenate([[float(loss)], m.flat_grad().cpu().numpy().astype(np.float64)]))
+'''
+
+
+def test_dropout_masks_do_not_depend_on_a_tiles_role(tmp_path):
+    """Full-size training step with dropout: the mixed ODE kernels (longest tiles four waves
+    wide, different split points forward and backward) must see exactly the masks of the
+    one-wave kernels (NJODE_ODE=mfma1), i.e. the same loss and gradient up to summation order."""
+    import os, subprocess, sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    repo = os.path.dirname(tests)
+    res = {}
+    for mode in ('mfma', 'mfma1'):
+        out = str(tmp_path / (mode + '.npy'))
+        env = dict(os.environ, NJODE_ODE=mode)
+        p = subprocess.run([sys.executable, '-c', _ROLE_SNIPPET.format(tests=tests, repo=repo, out=out)],
+                           env=env, cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout[-3000:]
+        res[mode] = np.load(out)
+    a, b = res['mfma'], res['mfma1']
+    assert a[0] == pytest.approx(b[0], rel=1e-5)
+    assert rel_l2(a[1:], b[1:]) < 1e-4
