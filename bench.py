@@ -124,7 +124,7 @@ def measured_traffic(kernel):
     try:
         with open(files[-1]) as f:
             d = json.load(f).get(kernel, {})
-        if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        if d.get('FETCH_SIZE') is not None and d.get('WRITE_SIZE') is not None:
             return int((d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024)
     except (OSError, ValueError):
         pass
