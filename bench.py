@@ -120,15 +120,15 @@ def measured_traffic(kernel):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*final_pmc_summary.json')))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
             d = json.load(f).get(kernel, {})
         if d.get('FETCH_SIZE') is not None and d.get('WRITE_SIZE') is not None:
-            return int((d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024)
+            return int((d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024), d.get('traffic_source')
     except (OSError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -251,7 +251,8 @@ def main():
                     'bound': 'mfma', 'kernel': dom, 'achieved': round(tf_k, 3),
                     'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
                     'frac': round(tf_k / FP32_MFMA_PEAK_TF, 5),
-                    'traffic': measured_traffic(dom),
+                    'traffic': measured_traffic(dom)[0],
+                    'traffic_source': measured_traffic(dom)[1],
                     'kernel_ms': round(dom_ms, 5),
                     'algorithmic_flops': int(2 * macs * euler_steps),
                     'note': 'f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak = f32 vector peak; '

@@ -14,7 +14,7 @@ constexpr int MAX_WAVES = 2048;
 // through the scalar cache, VALU with LDS-staged weights
 constexpr int ODE_MFMA = 0, ODE_VALU = 1, ODE_VALU_LDS = 2;
 // (NJODE_ODE=mfma1 keeps ODE_MFMA but with one wave per tile, njode_mfma.h, where the default
-// picks the four-waves-per-tile kernels of njode_mfma_split.h: A/B baseline)  // persistent gradient kernels: 256 CUs x 8 waves
+// picks the mixed kernels of njode_mfma_split.h: A/B baseline)
 
 struct CfgOps {
   NjodeDims dims;

@@ -14,13 +14,19 @@ hot path -- nothing of its experiment management (model-id registry, plots, Tele
   one batch in eval mode, ``model.epoch += 1``, ``model.weight_decay_step()``;
   ``train_loss`` logged = loss of the last batch of the epoch;
 * ``compute_optimal_eval_loss`` (``train.py:648-670``) from the analytic conditional
-  expectation; optional ``evaluate`` mean-square distance (``train.py:562-566``).
+  expectation; optional ``evaluate`` mean-square distance (``train.py:562-566``);
+* checkpoint / metric-file policy (``train.py:400-418, 585-621``) when ``model_path`` is
+  given: ``metric_id-<id>.csv`` with the reference's columns, ``last_checkpoint/`` every
+  ``save_every`` epochs and whenever the eval loss improves, ``best_checkpoint/`` on
+  improvement, ``resume_training`` / ``load_best`` to continue from them.
 
 The fused step (``NJODE.loss_and_grad`` + ``FusedAdam``) is used by default; pass
 ``fused=False`` to drive the model exactly like the reference does
 (``loss.backward()`` + ``torch.optim.Adam``).  With torch.distributed initialised the
 loop is data parallel (see ``parallel.py``).
 """
+import csv
+import os
 import time
 
 import numpy as np
@@ -62,7 +68,8 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
           enc_nn=((50, 'tanh'), (50, 'tanh')), use_rnn=False, solver='euler', weight=0.5,
           weight_decay=1., test_size=0.2, seed=398, device='cuda', fused=True,
           evaluate=False, shuffle_seed=0, log=print, max_steps_per_epoch=None,
-          device_collate=False, **options):
+          device_collate=False, model_path=None, model_id=1, save_every=1,
+          resume_training=False, load_best=False, **options):
     """Train on an in-memory dataset ``(stock_paths, observed_dates, nb_obs)`` with
     ``metadata`` as returned by ``data_utils.create_dataset``.  Returns
     ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch.
@@ -104,7 +111,38 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
 
     dev_ds = device_data.DeviceDataset.from_arrays(stock_paths, observed_dates, nb_obs, metadata,
                                                    device) if device_collate else None
+    # checkpoints and the metric file (reference train.py:344-350, 400-418)
+    columns = METR_COLUMNS + (['evaluation_mean_diff'] if evaluate else [])
+    best_eval_loss = np.inf
+    path_last = path_best = metric_file = None
+    saved_rows = []
+    if model_path is not None:
+        model_dir = os.path.join(model_path, 'id-{}'.format(model_id))
+        path_last = os.path.join(model_dir, 'last_checkpoint')
+        path_best = os.path.join(model_dir, 'best_checkpoint')
+        metric_file = os.path.join(model_dir, 'metric_id-{}.csv'.format(model_id))
+        os.makedirs(model_dir, exist_ok=True)
+        if resume_training and os.path.exists(os.path.join(
+                path_best if load_best else path_last, 'checkpt.tar')):
+            models.get_ckpt_model(path_best if load_best else path_last, model, optimizer, device)
+            if os.path.exists(metric_file):
+                with open(metric_file) as f:
+                    saved_rows = [[float(x) for x in r[1:]] for r in list(csv.reader(f))[1:]]
+                if saved_rows:
+                    best_eval_loss = min(r[4] for r in saved_rows)
+            model.epoch += 1
+            model.weight_decay_step()
+
+    def write_metrics():
+        # pandas' DataFrame.to_csv layout: unnamed index column first
+        with open(metric_file, 'w', newline='') as f:
+            wr = csv.writer(f)
+            wr.writerow([''] + columns)
+            for i, r in enumerate(saved_rows):
+                wr.writerow([i] + r)
+
     metrics = []
+    pending = []
     while model.epoch <= epochs:
         t0 = time.time()
         model.train()
@@ -160,8 +198,21 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             log("epoch {}, weight={:.5f}, train-loss={:.5f}, optimal-eval-loss={:.5f}, "
                 "eval-loss={:.5f}, ".format(model.epoch, model.weight, train_loss,
                                             opt_eval_loss, loss_val))
-        metrics.append([model.epoch, train_time, eval_time, train_loss, loss_val,
-                        opt_eval_loss] + row_extra)
+        row = [model.epoch, train_time, eval_time, train_loss, loss_val, opt_eval_loss] + row_extra
+        metrics.append(row)
+        pending.append(row)
+        if model_path is not None and rank == 0:
+            improved = loss_val < best_eval_loss
+            if model.epoch % save_every == 0 or improved:
+                saved_rows.extend(pending)
+                pending = []
+                write_metrics()
+                models.save_checkpoint(model, optimizer, path_last, model.epoch)
+            if improved:
+                log('save new best model: last-best-loss: {:.5f}, new-best-loss: {:.5f}, '
+                    'epoch: {}'.format(best_eval_loss, loss_val, model.epoch))
+                models.save_checkpoint(model, optimizer, path_best, model.epoch)
+                best_eval_loss = loss_val
         model.epoch += 1
         model.weight_decay_step()
     return model, metrics

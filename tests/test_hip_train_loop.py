@@ -77,3 +77,29 @@ def test_device_collated_loop_is_bit_identical():
                            device_collate=True, log=lambda s: None)
     assert torch.equal(m1.flat_parameters(), m2.flat_parameters())
     assert met1[1][3] == met2[1][3] and met1[1][4] == met2[1][4]
+
+
+def test_checkpoint_and_metric_file_policy(tmp_path):
+    """train.py:400-418, 585-621: metric csv with the reference's columns, last / best
+    checkpoints, and resuming continues from the saved epoch with the saved optimizer."""
+    import csv
+    import os
+    data, meta = _dataset(n=300)
+    kw = dict(batch_size=60, dropout_rate=0.0, log=lambda s: None, model_path=str(tmp_path),
+              model_id=7)
+    m1, met1 = train.train(data, meta, epochs=2, **kw)
+    d = os.path.join(str(tmp_path), 'id-7')
+    assert os.path.exists(os.path.join(d, 'last_checkpoint', 'checkpt.tar'))
+    assert os.path.exists(os.path.join(d, 'best_checkpoint', 'checkpt.tar'))
+    rows = list(csv.reader(open(os.path.join(d, 'metric_id-7.csv'))))
+    assert rows[0] == [''] + train.METR_COLUMNS and len(rows) == 3
+    assert float(rows[2][5]) == pytest.approx(met1[1][4])
+    # three epochs in one go == two epochs, then resume for the third
+    m2, met2 = train.train(data, meta, epochs=3, resume_training=True, **kw)
+    m3, met3 = train.train(data, meta, epochs=3, batch_size=60, dropout_rate=0.0,
+                           log=lambda s: None)
+    assert len(met2) == 1 and met2[0][0] == 3
+    np.testing.assert_allclose(m2.flat_parameters().cpu().numpy(),
+                               m3.flat_parameters().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    ck = torch.load(os.path.join(d, 'last_checkpoint', 'checkpt.tar'), weights_only=False)
+    assert set(ck) == {'epoch', 'weight', 'model_state_dict', 'optimizer_state_dict'}
