@@ -184,7 +184,8 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       FS::ode,
       FS::ode + FS::enc,
       HAS_MFMA_SWEEP ? 1 : 0,
-      HAS_SPLIT ? 1 : 0};
+      HAS_SPLIT ? 1 : 0,
+      HAS_MFMA ? 1 : 0};
   return &ops;
 }
 #endif

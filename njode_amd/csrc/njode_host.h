@@ -34,7 +34,8 @@ struct CfgOps {
   int frag_floats;  // size of the fragment buffer (0: no MFMA kernels for this shape)
   int frag_enc_off, frag_dec_off;  // offsets of the encoder / readout fragments in it
   int lock_sweep_mfma;  // the lockstep backward has a matrix-core adjoint sweep
-  int ode_split;        // ODE_MFMA runs the four-waves-per-tile ODE kernels (one slab row per block)
+  int ode_split;        // ODE_MFMA runs the mixed ODE kernels (njode_mfma_split.h)
+  int seg_mfma;         // the segment plan has matrix-core kernels for this shape
 };
 
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events

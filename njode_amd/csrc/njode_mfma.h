@@ -359,7 +359,8 @@ template <class C> struct OdeBwdSingleLds {
   static constexpr int FLOATS = 4 * 2 * IMG_FLOATS + OdeLdsFrags<C>::NVEC * 64;
 };
 // one 256-thread block = 4 independent workers; worker `wave` of `n_waves` walks the tiles
-// [tile0, tile1) in snake order and flushes its gradient tiles into slab row `slab_row`
+// [tile0, tile1) in snake order; the block's workers sum their gradient tiles into slab row
+// `slab_row`
 template <class C, bool DROP>
 NJ_DEV void ode_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
                            int slab_row) {
@@ -528,7 +529,36 @@ NJ_DEV void ode_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, i
     }
   }
 
-  // ---- flush the register tiles into this wave's slab (parameter layout)
+  // ---- flush: the block's four workers share ONE slab row (parameter layout), so the
+  // reduction kernels read one row per block, not per wave.  Waves 1-3 park their register
+  // tiles in LDS (free by now), wave 0 adds them in fixed order (deterministic) and stores.
+  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
+  static_assert(3 * NG * 64 * 4 <= OdeBwdSingleLds<C>::FLOATS, "tile reduction does not fit the LDS");
+  __syncthreads();
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
+  auto for_tiles = [&](auto f) {
+    int i = 0;
+#pragma unroll
+    for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT0; ++nt) f(G1[mt][nt], i++);
+  };
+  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+  __syncthreads();
+  if (wv != 0) return;
+  for_tiles([&](f32x4& t, int i) {
+    t += red[(0 * NG + i) * 64 + lane];
+    t += red[(1 * NG + i) * 64 + lane];
+    t += red[(2 * NG + i) * 64 + lane];
+  });
   float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
   float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
         *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
@@ -571,7 +601,7 @@ template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) k_ode_bwd_mfma(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdSingleLds<C>::FLOATS];
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, gridDim.x * 4, 0, (a.n_obs + 15) / 16, wave);
+  ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, gridDim.x * 4, 0, (a.n_obs + 15) / 16, blockIdx.x);
 }
 
 }  // namespace njode

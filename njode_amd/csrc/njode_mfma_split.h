@@ -459,7 +459,7 @@ template <class C> struct OdeBwdMixedLds {
   static constexpr int A = OdeBwdSingleLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;
   static constexpr int FLOATS = A > B ? A : B;
 };
-// slab rows: [0, ns) the split blocks, then one per single-wave worker
+// one slab row per block
 template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdMixedLds<C>::FLOATS];
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
     ode_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
   } else {
     const int wave = ((int)blockIdx.x - ns) * 4 + (threadIdx.x >> 6);
-    ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, ns + wave);
+    ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
   }
 }
 
