@@ -71,6 +71,9 @@ typedef struct NjodeDims {
 #define NJODE_C_GET_LOSS 0x2    /* get_loss=True                                  */
 #define NJODE_C_RETURN_PATH 0x4 /* return_path=True                               */
 #define NJODE_C_SAVE_BWD 0x8    /* keep what njode_backward_f32 needs in workspace */
+#define NJODE_C_LOSS_IN_BWD 0x10 /* fused step: the loss may be produced by the backward call
+                                   (njode_backward_loss_f32, same `loss` pointer) instead of
+                                   the forward call -- saves one pass over the observation rows */
 
 /*
  * Time grid of one forward pass: the float64 clock of NJODE.forward
@@ -167,6 +170,21 @@ int njode_backward_f32(const NjodeDims* dims, const float* params,
                        uint64_t seed, const float* grad_loss, float* grad_params,
                        void* workspace, size_t workspace_bytes,
                        njodeStream_t stream);
+
+/*
+ * Fused training step (model(...) followed by loss.backward(), train.py:510-522, with
+ * grad_loss = 1): njode_forward_f32(..., flags | NJODE_C_LOSS_IN_BWD, ..., loss, ...) followed
+ * by this call with the same flags and the same `loss` pointer.  Where the plan allows it the
+ * forward skips its readout/loss pass over the observation rows and this call, which
+ * evaluates the same readouts for their gradients anyway, writes the loss; otherwise the
+ * forward has already written it and this call leaves it alone.
+ */
+int njode_backward_loss_f32(const NjodeDims* dims, const float* params,
+                            const NjodeBatch* batch, const NjodeSchedule* sched,
+                            int32_t call_flags, float weight, float dropout_p,
+                            uint64_t seed, const float* grad_loss, float* grad_params,
+                            float* loss, void* workspace, size_t workspace_bytes,
+                            njodeStream_t stream);
 
 /*
  * Replaces torch.optim.Adam(lr, betas, eps, weight_decay).step() on the flat

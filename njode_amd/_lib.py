@@ -16,10 +16,11 @@ NJODE_OK = 0
 E_UNSUPPORTED, E_BADARG, E_WORKSPACE, E_HIP = 1, 2, 3, 4
 ACT_TANH, ACT_RELU = 0, 1
 F_MASKED, F_INPUT_CURRENT_T, F_RESIDUAL, F_LOSS_EASY, F_USE_RNN = 0x1, 0x2, 0x4, 0x8, 0x10
-C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD = 0x1, 0x2, 0x4, 0x8
+C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD, C_LOSS_IN_BWD = 0x1, 0x2, 0x4, 0x8, 0x10
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
-           'njode_forward_f32', 'njode_backward_f32', 'njode_adam_step_f32',
+           'njode_forward_f32', 'njode_backward_f32', 'njode_backward_loss_f32',
+           'njode_adam_step_f32',
            'njode_last_error', 'njode_build_info', 'njode_profile_enable',
            'njode_profile_read',
            # include/njode_producer.h
@@ -96,6 +97,10 @@ def lib():
                                      C.POINTER(NjodeSchedule), i32, f32, f32, u64,
                                      vp, vp, vp, sz, vp]
     L.njode_backward_f32.restype = C.c_int
+    L.njode_backward_loss_f32.argtypes = [C.POINTER(NjodeDims), vp, C.POINTER(NjodeBatch),
+                                          C.POINTER(NjodeSchedule), i32, f32, f32, u64,
+                                          vp, vp, vp, vp, sz, vp]
+    L.njode_backward_loss_f32.restype = C.c_int
     L.njode_adam_step_f32.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32,
                                       f32, vp]
     L.njode_adam_step_f32.restype = C.c_int

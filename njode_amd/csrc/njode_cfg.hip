@@ -145,7 +145,7 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma.tails" : "k_ode_fwd_items.tails", st);
       launch_ode_fwd<DROP, true, ODE>(a, st);
     }
-    {
+    if (!(ODE == ODE_MFMA && a.defer_loss)) {
       ProfScope ps(ODE == ODE_MFMA ? "k_jump_rows_mfma" : "k_jump_rows", st);
       if constexpr (ODE == ODE_MFMA) launch_mfma_jump<C, DROP>(a, st);
       else k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);

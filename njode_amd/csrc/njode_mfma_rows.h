@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(256, 2) k_jump_rows_bwd_mfma(KArgs a) {
 #pragma unroll
     for (int i = 0; i < C::D; ++i) mask[i] = 1.0f;
     const float scale = (valid ? a.inv_batch : 0.0f) * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
-    loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+    const float term = loss_row<C>(x, mask, y, ybj, a.weight, a.loss_easy, scale, dy, dybj);
+    if (a.defer_loss && valid && g == 0) a.loss_terms[r] = term;   // fused step: the loss itself
     // backward through y = readout(h0row[r])
     fill_by_group<S::QO, C::DO>(dq, dy, g);
     mnet_bwd<S, C::ACT, DROP, true>(Bf, G, img_d, img_a, dq, b0, a1, a2, k1, k2, a.dc.inv_keep,

@@ -492,9 +492,18 @@ class NJODE(torch.nn.Module):
         self._ring.release_after(slot_i, stream)
         _lib.check(rc)
 
-    def _run_backward(self, call, grad_loss, grad_flat):
+    def _run_backward(self, call, grad_loss, grad_flat, loss=None):
+        """``loss`` given: the fused step's backward, which may also produce the loss
+        (``NJODE_C_LOSS_IN_BWD``, see ``loss_and_grad``)."""
         L = _lib.lib()
         stream = torch.cuda.current_stream()
+        if loss is not None:
+            _lib.check(L.njode_backward_loss_f32(
+                ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),
+                ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
+                grad_loss.data_ptr(), grad_flat.data_ptr(), loss.data_ptr(), call.ws.data_ptr(),
+                call.ws.numel(), stream.cuda_stream))
+            return
         _lib.check(L.njode_backward_f32(
             ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),
             ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
@@ -544,7 +553,10 @@ class NJODE(torch.nn.Module):
         """Forward + exact gradient in two library calls, no autograd bookkeeping:
         returns ``(None, loss)`` (device loss tensor; hT is not computed -- it would
         cost a per-path tail evolve nobody reads) and fills ``flat_grad()`` (whose
-        slices are the parameters' ``.grad``).  Used by the build's harness and bench."""
+        slices are the parameters' ``.grad``).  The calls carry ``NJODE_C_LOSS_IN_BWD``:
+        on the segment plan the forward skips its readout/loss pass over the observation
+        rows and the backward, which evaluates the same readouts anyway, writes the loss.
+        Used by the build's harness and bench."""
         grad = self.flat_grad()
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
@@ -555,11 +567,12 @@ class NJODE(torch.nn.Module):
         # per-path tail evolve; the lockstep plan produces it anyway
         hT = (torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
               if self.masked else None)
+        call.flags |= _lib.C_LOSS_IN_BWD
         try:
             self._run_forward(call, hT, loss, None, None, slot_i)
             if self._ones is None or self._ones.device != dev:
                 self._ones = torch.ones(1, dtype=torch.float32, device=dev)
-            self._run_backward(call, self._ones, grad)
+            self._run_backward(call, self._ones, grad, loss=loss)
         finally:
             self._release_ws(call)
         return hT, loss.reshape(())
