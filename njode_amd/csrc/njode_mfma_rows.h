@@ -109,6 +109,38 @@ template <class S> struct GradTiles {
       for (int n = 0; n < S::NT0; ++n) G1[i][n] = z;
     }
   }
+  static constexpr int NG = S::MTO * S::NT1 + S::MT1 * S::NT1 + S::MT1 * S::NT0;
+  template <class F> NJ_DEV void for_tiles(F f) {
+    int i = 0;
+#pragma unroll
+    for (int mt = 0; mt < S::MTO; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < S::NT1; ++nt) f(G3[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < S::NT1; ++nt) f(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < S::NT0; ++nt) f(G1[mt][nt], i++);
+  }
+  // Sum the four waves' tiles of a 256-thread block into wave 0's (fixed order:
+  // deterministic), through `lds` (>= 3 * NG * 256 floats, free by now): the block then
+  // stores ONE slab row.  Returns true for the wave that holds the sum.
+  NJ_DEV bool reduce_block(lfp lds, int wv, int lane) {
+    f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds;
+    __syncthreads();
+    if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+    __syncthreads();
+    if (wv != 0) return false;
+    for_tiles([&](f32x4& t, int i) {
+      t += red[(0 * NG + i) * 64 + lane];
+      t += red[(1 * NG + i) * 64 + lane];
+      t += red[(2 * NG + i) * 64 + lane];
+    });
+    return true;
+  }
   // store into a slab laid out like the network's parameters (NL offsets)
   template <class NL> NJ_DEV void flush(float* slab, int g, int c) const {
     float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
@@ -490,7 +522,9 @@ __global__ void __launch_bounds__(256, 2) k_jump_rows_bwd_mfma(KArgs a) {
                                     a.dc.inv_keep, a.keep, din, g, c);
     dec_input_grad<C, S>(din, b0, dybj, valid ? a.lam_end + (size_t)r * C::H : trash, trash, g);
   }
-  G.template flush<NL>(a.slab + (size_t)wave * C::P + C::OFF_DEC, g, c);
+  static_assert(3 * GradTiles<S>::NG * 256 <= 4 * 2 * IMG_FLOATS + S::NALL * 64, "tile reduction does not fit");
+  if (G.reduce_block((lfp)lds_raw, wv, lane))
+    G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_DEC, g, c);
 }
 
 // ---- D: d loss / d encoder params -----------------------------------------------------------
@@ -541,7 +575,9 @@ __global__ void __launch_bounds__(256, 2) k_encode_rows_bwd_mfma(KArgs a) {
     mnet_bwd<S, C::ACT, DROP, false>(Bf, G, img_d, img_a, gh, b0, a1, a2, k1, k2, a.dc.inv_keep,
                                      a.keep, din, g, c);
   }
-  G.template flush<NL>(a.slab + (size_t)wave * C::P + C::OFF_ENC, g, c);
+  static_assert(3 * GradTiles<S>::NG * 256 <= 4 * 2 * IMG_FLOATS + S::NALL * 64, "tile reduction does not fit");
+  if (G.reduce_block((lfp)lds_raw, wv, lane))
+    G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_ENC, g, c);
 }
 
 }  // namespace njode
