@@ -144,12 +144,15 @@ def test_shipped_checkpoint_known_answers(tag, name):
     assert msd == pytest.approx(float(g['msd_cond_exp']), rel=1e-3)
 
 
-def test_larger_batch_loss_and_grads_vs_oracle():
-    """B = 1500 seeded Black-Scholes batch, random-init weights: both plans and the
-    gradient against the CPU oracle."""
+@pytest.mark.parametrize('n_paths', [700, 1500])
+def test_larger_batch_loss_and_grads_vs_oracle(n_paths):
+    """Seeded Black-Scholes batches, random-init weights: both plans and the gradient against
+    the CPU oracle.  The sizes straddle the regimes of the mixed ODE kernels (700 paths: ~440
+    tiles, backward mixed / forward all four-wide; 1 500 paths: ~940 tiles, both mixed), and
+    the fused step (loss written by the backward) is checked on the same batch."""
     torch.manual_seed(1)
     cfg = demo_cfg()
-    b, meta = bs_batch(1500, seed=3)
+    b, meta = bs_batch(n_paths, seed=3)
     m = hip_model(cfg).train()
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     (h_o, l_o), params = oracle_forward(cfg, sd, b, meta['dt'], meta['maturity'], grads=True)
@@ -162,6 +165,12 @@ def test_larger_batch_loss_and_grads_vs_oracle():
     got = grads_by_name(m)
     for k, p in params.items():
         assert rel_l2(got[k], p.grad.numpy()) < GRAD_REL_L2, k
+    d = to_dev(b)               # fused step: forward without the row pass, loss from the backward
+    _, loss_f = m.loss_and_grad(d['times'], d['time_ptr'], d['X'], d['obs_idx'], meta['dt'],
+                                meta['maturity'], d['start_X'], d['n_obs_ot'])
+    assert float(loss_f) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+    flat_ref = np.concatenate([params[k].grad.numpy().reshape(-1) for k in sd])
+    assert rel_l2(m.flat_grad().cpu().numpy(), flat_ref) < GRAD_REL_L2
     m.eval()
     with torch.no_grad():   # lockstep plan on the same batch
         hT2, loss2, _, _, path_y = hip_forward(m, b, meta['dt'], meta['maturity'],
