@@ -494,10 +494,11 @@ __global__ void __launch_bounds__(256, 2) k_jump_rows_bwd_mfma(KArgs a) {
     float dy[C::DO], dybj[C::DO], dq[S::QO];
     f32x4 out[S::MTO], din[S::MTI];
     uint32_t kb1, kb2, k1, k2;
-    // y_bj (activations discarded), then y (activations kept)
-    dec_input<C, S>(he, b0, g);
+    // y_bj, then y: both evaluations' activations stay in registers for their backward
+    float b0b[S::Q0], a1b[S::Q1], a2b[S::Q1];
+    dec_input<C, S>(he, b0b, g);
     row_keep_bits<DROP>(a, gid, tkey, NET_DEC_BJ, g, S::Q1, kb1, kb2);
-    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, kb1, kb2, a.dc.inv_keep, g);
+    mnet_fwd<S, C::ACT, DROP>(F, b0b, a1b, a2b, out, kb1, kb2, a.dc.inv_keep, g);
     dec_collect<C, S>(img_d, out, he, ybj, g, c);
     dec_input<C, S>(h0, b0, g);
     row_keep_bits<DROP>(a, gid, tkey, NET_DEC, g, S::Q1, k1, k2);
@@ -514,13 +515,11 @@ __global__ void __launch_bounds__(256, 2) k_jump_rows_bwd_mfma(KArgs a) {
     mnet_bwd<S, C::ACT, DROP, true>(Bf, G, img_d, img_a, dq, b0, a1, a2, k1, k2, a.dc.inv_keep,
                                     a.keep, din, g, c);
     dec_input_grad<C, S>(din, b0, dy, valid ? a.g_h0 + (size_t)r * C::H : trash, trash, g);
-    // backward through y_bj = readout(h_end[r]) (recompute its activations)
-    dec_input<C, S>(he, b0, g);
-    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, kb1, kb2, a.dc.inv_keep, g);
+    // backward through y_bj = readout(h_end[r])
     fill_by_group<S::QO, C::DO>(dq, dybj, g);
-    mnet_bwd<S, C::ACT, DROP, true>(Bf, G, img_d, img_a, dq, b0, a1, a2, kb1, kb2,
+    mnet_bwd<S, C::ACT, DROP, true>(Bf, G, img_d, img_a, dq, b0b, a1b, a2b, kb1, kb2,
                                     a.dc.inv_keep, a.keep, din, g, c);
-    dec_input_grad<C, S>(din, b0, dybj, valid ? a.lam_end + (size_t)r * C::H : trash, trash, g);
+    dec_input_grad<C, S>(din, b0b, dybj, valid ? a.lam_end + (size_t)r * C::H : trash, trash, g);
   }
   static_assert(3 * GradTiles<S>::NG * 256 <= 4 * 2 * IMG_FLOATS + S::NALL * 64, "tile reduction does not fit");
   if (G.reduce_block((lfp)lds_raw, wv, lane))
