@@ -154,6 +154,29 @@ NJ_DEV void hidden_from_acc(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q
   hidden_from_acc_g<MF<C>::MT1, MF<C>::Q1, MF<C>::W, C::ACT, DROP>(acc, av, keep, inv_keep, g);
 }
 
+// Forward-only form: draws the layer's keep decisions from the stream and applies them at once
+// (the same words, in the same order, as keep_bits<Q1> + hidden_from_acc: identical masks),
+// without assembling and re-testing a bit mask.
+template <class C, bool DROP>
+NJ_DEV void hidden_from_acc_draw(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q1], uint32_t& s,
+                                 uint32_t thr16, float inv_keep, int g) {
+  constexpr int Q1 = MF<C>::Q1;
+#pragma unroll
+  for (int q = 0; q < Q1; q += 2) {
+    float v0 = act_f<C::ACT>(acc[q / 4][q % 4]);
+    float v1 = q + 1 < Q1 ? act_f<C::ACT>(acc[(q + 1) / 4][(q + 1) % 4]) : 0.0f;
+    if constexpr (DROP) {
+      s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+      v0 = (s & 0xffffu) >= thr16 ? v0 * inv_keep : 0.0f;
+      v1 = (s >> 16) >= thr16 ? v1 * inv_keep : 0.0f;
+    }
+    av[q] = v0;
+    if (q + 1 < Q1) av[q + 1] = v1;
+  }
+  constexpr int QB = MF<C>::W / 4, GB = MF<C>::W % 4;
+  av[QB] = g == GB ? 1.0f : av[QB];
+}
+
 // B (MFMA): Euler evolve of every item; 16 items per wave, persistent over tiles.
 // worker `wave` of `n_waves` walks the tiles [tile0, tile1) in snake order
 template <class C, bool DROP, bool TAIL>
@@ -226,13 +249,11 @@ NJ_DEV void ode_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int 
       }
       float b0[M::Q0];
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
-      uint32_t k1 = 0, k2 = 0;
+      uint32_t st = 0;
       if constexpr (DROP) {
         const unsigned long long gid = a.gid0 + it.b;
-        uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
-                                 (uint32_t)k, NET_ODE);
-        k1 = keep_bits<M::Q1>(st, a.dc.thr16);
-        k2 = keep_bits<M::Q1>(st, a.dc.thr16);
+        st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                        (uint32_t)k, NET_ODE);
       }
       f32x4 acc[M::MT1];
       float a1[M::Q1], a2[M::Q1];
@@ -242,14 +263,14 @@ NJ_DEV void ode_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int 
       for (int q = 0; q < M::Q0; ++q)
 #pragma unroll
         for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A1[mt][q], b0[q], acc[mt]);
-      hidden_from_acc<C, DROP>(acc, a1, k1, a.dc.inv_keep, g);
+      hidden_from_acc_draw<C, DROP>(acc, a1, st, a.dc.thr16, a.dc.inv_keep, g);
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < M::Q1; ++q)
 #pragma unroll
         for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(A2[mt][q], a1[q], acc[mt]);
-      hidden_from_acc<C, DROP>(acc, a2, k2, a.dc.inv_keep, g);
+      hidden_from_acc_draw<C, DROP>(acc, a2, st, a.dc.thr16, a.dc.inv_keep, g);
       f32x4 acch[M::MTH];
 #pragma unroll
       for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
