@@ -50,8 +50,10 @@ int njode_philox4x32_10(int32_t n, const uint32_t* ctr, const uint32_t* key, uin
                         njodeStream_t stream);
 
 /* Euler-Maruyama paths of `sde` into paths_tm f64 [S+1][dim][N].
- * normals == NULL : standard normals from Philox4x32-10 keyed by `seed`, counter =
- *                   (path, step, dim); Box-Muller on 53-bit uniforms.
+ * normals == NULL : standard normals from Philox4x32-10 keyed by `seed`, Box-Muller on 53-bit
+ *                   uniforms; counter = (path, step, dim) for Heston (both normals of the
+ *                   pair are used by one step), (path, ceil(step / 2), dim) otherwise (the
+ *                   pair feeds steps 2m - 1 and 2m).
  * normals != NULL : device f64 array in the reference's draw order, [N][S][dim]
  *                   (Heston: [N][S][2][dim]); the recurrences then reproduce the reference's
  *                   float64 arithmetic operation by operation. */

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) k_generate(NjodeSde p, double dt, double 
   const long long n = tid % N;
   const size_t slice = (size_t)p.dim * N;
   double* out = paths + (size_t)j * N + n;
-  double s = p.S0, v = p.mean;
+  double s = p.S0, v = p.mean, z_next = 0.0;
   out[0] = s;
   for (int k = 1; k <= p.n_steps; ++k) {
     double z1, z2;
@@ -103,10 +103,20 @@ __global__ void __launch_bounds__(256) k_generate(NjodeSde p, double dt, double 
         z1 = normals[((size_t)n * p.n_steps + (k - 1)) * p.dim + j];
         z2 = 0.0;
       }
-    } else {
+    } else if (MODEL == NJODE_SDE_HESTON) {
       const U4 r = philox4x32_10(U4{(uint32_t)n, (uint32_t)(n >> 32), (uint32_t)k, (uint32_t)j},
                                  seed_lo, seed_hi ^ STREAM_PATHS);
       normal_pair(r, z1, z2);
+    } else {
+      // one Philox call and one Box-Muller pair feed two consecutive steps (2m - 1, 2m)
+      if (k & 1) {
+        const U4 r = philox4x32_10(U4{(uint32_t)n, (uint32_t)(n >> 32), (uint32_t)((k + 1) >> 1),
+                                      (uint32_t)j}, seed_lo, seed_hi ^ STREAM_PATHS);
+        normal_pair(r, z1, z_next);
+      } else {
+        z1 = z_next;
+      }
+      z2 = 0.0;
     }
     const double tk = (double)(k - 1) * dt;
     const double pc = p.has_sine ? 1.0 + sin(p.sine_coeff * tk) : 1.0;

@@ -57,8 +57,21 @@ def observation_uniforms(n_paths, n_steps, seed):
     return out[:, :n_steps + 1]
 
 
+def step_normals(n_paths, n_steps, dim, seed):
+    """The per-step normals of the Black-Scholes / OU generators: the Box-Muller pair of
+    counter (path, m, dim) feeds steps 2m - 1 (cos branch) and 2m (sin branch); f64
+    [N, S, dim]."""
+    m = (n_steps + 1) // 2
+    z1, z2 = path_normals(n_paths, m, dim, seed)
+    z = np.empty((n_paths, 2 * m, dim))
+    z[:, 0::2, :] = z1
+    z[:, 1::2, :] = z2
+    return z[:, :n_steps, :]
+
+
 def path_normals(n_paths, n_steps, dim, seed):
-    """The normal pairs njode_generate_paths draws: (z1, z2) f64 [N, S, dim] each."""
+    """Box-Muller pairs of the counters (path, 1..n_steps, dim): (z1, z2) f64 [N, S, dim] each
+    (Heston consumes one pair per step)."""
     lo, hi = seed & 0xFFFFFFFF, ((seed >> 32) & 0xFFFFFFFF) ^ STREAM_PATHS
     n, k, j = np.meshgrid(np.arange(n_paths, dtype=np.uint32),
                           np.arange(1, n_steps + 1, dtype=np.uint32),

@@ -65,7 +65,7 @@ def test_philox_driven_generation_follows_the_oracle_stream():
     hp = dict(HP, nb_paths=64, nb_steps=30)
     ds = device_data.DeviceDataset.generate('BlackScholes', hp, seed=0x1234567890ab)
     got_paths, got_obs, _ = ds.to_arrays()
-    z1, _ = po.path_normals(64, 30, 1, seed=0x1234567890ab)
+    z1 = po.step_normals(64, 30, 1, seed=0x1234567890ab)
     dt = hp['maturity'] / 30
     ref = np.empty((64, 1, 31))
     ref[:, :, 0] = hp['S0']

@@ -43,6 +43,11 @@ def test_oracle_streams_have_the_right_moments():
         assert abs(z.mean()) < 4 / np.sqrt(z.size)
         assert abs(z.var() - 1.0) < 4 * np.sqrt(2.0 / z.size)
     assert abs(np.mean(z1 * z2)) < 4 / np.sqrt(z1.size)
+    zs = po.step_normals(50, 7, 2, seed=3)          # odd step count: the last pair is half used
+    a, b = po.path_normals(50, 4, 2, seed=3)
+    assert zs.shape == (50, 7, 2)
+    np.testing.assert_array_equal(zs[:, 0::2], a)
+    np.testing.assert_array_equal(zs[:, 1::2], b[:, :3])
 
 
 def test_times_from_counts_reproduces_the_collate_clock():
