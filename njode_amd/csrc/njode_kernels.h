@@ -47,6 +47,8 @@ struct KArgs {
   float* frag;      // MFMA A-fragments of the ODE network (k_pack_frags)
   float* frag_enc;  // ... of the encoder and the readout (k_pack_net)
   float* frag_dec;
+  float* frag2;     // scaled A-fragments of the ODE network (k_pack_frags2, njode_ode2.h)
+  const void* fragx;  // split-bf16 A-fragments of the ODE network (k_pack_frags_x, njode_odex.h)
   // batch
   int B, n_obs;
   const float* start_X;

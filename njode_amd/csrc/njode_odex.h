@@ -1,0 +1,1192 @@
+// njode_odex.h -- ODE kernels of the segment plan on the 16-bit matrix cores with split
+// fp32 operands ("3 x bf16" pieces, 6 partial products; cf. BF16x9 / 3xTF32 emulation).
+//
+// Why (profiles/r02_pipe_ubench.jsonl, tools/ubench/pipe_ubench.hip): on gfx950
+// v_mfma_f32_16x16x4_f32 and the vector ALU are ONE pipe -- an f32 MFMA wave and a VALU wave
+// on the same SIMD take the sum of their times, at any occupancy -- so the f32 kernels of
+// njode_mfma.h / njode_ode2.h are bound by (33 cycles x MFMAs) + (VALU cycles), and 27 % of
+// their MFMAs are tile padding.  v_mfma_f32_16x16x32_bf16 runs on the matrix pipe proper:
+// 17 cycles for 8 192 MACs (f32: 33 for 1 024) and it overlaps with VALU work.
+//
+// Numerics.  An fp32 value a is split EXACTLY into three bf16 pieces a = a0 + a1 + a2 (8 + 8
+// + 8 significand bits; truncation, each remainder is exact in fp32), a product a b is the sum
+// of the six partial products a_i b_j with i + j <= 2 (each exact in fp32, the three dropped
+// ones are < 2^-24 |a b|), accumulated in fp32 by the MFMA.  The result differs from an fp32
+// fmaf chain only at the level of fp32 rounding itself (tests: same tolerances as the f32
+// kernels; tools/ubench reports the difference between the two paths).
+//
+// Layout (16 chains per wave, v_mfma_f32_16x16x32: A[row l&15][k = 8 (l>>4) + j],
+// B[k = 8 (l>>4) + j][col l&15], D[row 4 (l>>4) + r][col l&15]; lane l = (g, c)):
+//   * a hidden vector (W units + the constant-1 bias unit, <= 64) lives as 16 values per lane:
+//     value (ks, j) is unit 32 ks + 8 g + j of chain c -- exactly this lane's B-operand slots
+//     of k-step ks.  Output tile mt of a hidden layer is assigned the units
+//     32 (mt>>1) + 8 (i>>2) + 4 (mt&1) + (i&3) (i = row), so D register r of tile mt IS value
+//     (ks = mt>>1, j = 4 (mt&1) + r): activations flow from layer to layer inside the lane.
+//   * the ODE input vector is kept compact: entry n < H is tanh(h_n), entries H .. H+NE-1 are
+//     [x (D), tau, t - tau, (t), 1]; lane (g, c) holds entries 4g .. 4g+3 (slots j < 4) and
+//     16 + 4g .. 16 + 4g+3 (slots j >= 4); the H-wide output tile uses natural rows, so its D
+//     registers are entries 4g .. 4g+3 again.
+//   * dW needs the chain index on k: each packed B operand is stored as it is into an LDS
+//     image [chain][unit] (one ds_write_b128 per k-step and piece) and read back transposed
+//     with ds_read_b64_tr_b16 -- no shuffles, no per-element LDS writes.
+#pragma once
+#include "njode_ode2.h"
+
+namespace njode {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// NJ_XSCHEME 0: three bf16 pieces, six products (fp32-exact class); 1: two f16 pieces, three
+// products ("3xFP16", 22-bit class: like 3xTF32; values must sit inside f16's range).
+#ifndef NJ_XSCHEME
+#define NJ_XSCHEME 0
+#endif
+#if NJ_XSCHEME == 0
+constexpr int XNP = 3;                       // pieces per value
+constexpr int XNPROD = 6;                    // partial products i + j <= 2
+// product list, largest first
+__device__ constexpr int XPI[XNPROD] = {0, 0, 1, 0, 1, 2};
+__device__ constexpr int XPJ[XNPROD] = {0, 1, 0, 2, 1, 0};
+
+NJ_DEV f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                 __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// exact 3-piece split of two values; piece p of (v0, v1) packed as (lo half, hi half)
+NJ_DEV void split2(float v0, float v1, uint32_t (&p)[XNP]) {
+  const uint32_t u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+  p[0] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  const float r0 = v0 - __uint_as_float(u0 & 0xffff0000u), r1 = v1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t s0 = __float_as_uint(r0), s1 = __float_as_uint(r1);
+  p[1] = __builtin_amdgcn_perm(s1, s0, 0x07060302u);
+  const float q0 = r0 - __uint_as_float(s0 & 0xffff0000u), q1 = r1 - __uint_as_float(s1 & 0xffff0000u);
+  p[2] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+// host-side / pack-kernel version for one value
+NJ_DEV void split1(float v, uint16_t (&p)[XNP]) {
+  uint32_t u = __float_as_uint(v);
+  p[0] = (uint16_t)(u >> 16);
+  float r = v - __uint_as_float(u & 0xffff0000u);
+  u = __float_as_uint(r);
+  p[1] = (uint16_t)(u >> 16);
+  r = r - __uint_as_float(u & 0xffff0000u);
+  p[2] = (uint16_t)(__float_as_uint(r) >> 16);
+}
+#else
+constexpr int XNP = 2;
+constexpr int XNPROD = 3;
+__device__ constexpr int XPI[XNPROD] = {0, 0, 1};
+__device__ constexpr int XPJ[XNPROD] = {0, 1, 0};
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+NJ_DEV f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+NJ_DEV void split2(float v0, float v1, uint32_t (&p)[XNP]) {
+  const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+  p[0] = __builtin_bit_cast(uint32_t, h);
+  const float r0 = v0 - (float)h[0], r1 = v1 - (float)h[1];
+  p[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
+NJ_DEV void split1(float v, uint16_t (&p)[XNP]) {
+  uint32_t q[XNP];
+  split2(v, 0.0f, q);
+  p[0] = (uint16_t)(q[0] & 0xffffu);
+  p[1] = (uint16_t)(q[1] & 0xffffu);
+}
+#endif
+
+// ---- shapes ---------------------------------------------------------------------------
+template <class C> struct XF {
+  static constexpr int H = C::H, D = C::D, W = C::W;
+  static constexpr int NE = D + (C::CURT ? 3 : 2) + 1;   // extras: x, tau, tdiff, (t), one
+  static constexpr int KS1 = (W + 1 + 31) / 32;           // k-steps over a hidden vector (+ bias unit)
+  static constexpr int MT1 = 2 * KS1;                     // output tiles of a hidden layer
+  static constexpr int NIN = H + NE;                      // compact ODE input entries
+  static constexpr int NT0 = (NIN + 15) / 16;             // their 16-column groups
+  static constexpr bool OK = C::NH == 2 && H <= 16 && NIN <= 32 && W <= 63 && !C::MASKED && !C::RNN;
+  // fragment table: [fragment][piece][lane] of 16-byte vectors
+  static constexpr int F1 = 0;                            // S [W1 | b1]        MT1 x 1
+  static constexpr int F2 = F1 + MT1;                     // S [ik W2 | b2]     MT1 x KS1
+  static constexpr int F3 = F2 + MT1 * KS1;               // [ik W3 | b3]       1 x KS1
+  static constexpr int NFWD = F3 + KS1;
+  static constexpr int B3 = NFWD;                         // ik W3^T            MT1 x 1
+  static constexpr int B2 = B3 + MT1;                     // ik W2^T            MT1 x KS1
+  static constexpr int B1 = B2 + MT1 * KS1;               // W1^T (h rows)      1 x KS1
+  static constexpr int NALL = B1 + KS1;
+  static constexpr int VEC_BYTES = NALL * XNP * 64 * 16;
+  // unit of row i of hidden output tile mt / of k-slot (ks, g, j)
+  static constexpr int hid_row_unit(int mt, int i) { return 32 * (mt >> 1) + 8 * (i >> 2) + 4 * (mt & 1) + (i & 3); }
+  static constexpr int hid_slot_unit(int ks, int g, int j) { return 32 * ks + 8 * g + j; }
+  // compact input entry of k-slot (g, j)
+  static constexpr int in_slot_entry(int g, int j) { return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4); }
+};
+// value of W1's column / the bias for compact input entry n (reference order [x, h, tau, tdiff, (t)])
+template <class C> NJ_DEV float w1_entry(const float* W1, const float* b1, int uo, int n) {
+  using X = XF<C>;
+  constexpr int IN0 = C::ODE_IN;
+  if (n < X::H) return W1[uo * IN0 + C::D + n];
+  const int e = n - X::H;
+  if (e < C::D) return W1[uo * IN0 + e];
+  if (e < X::NE - 1) return W1[uo * IN0 + C::D + X::H + (e - C::D)];
+  if (e == X::NE - 1) return b1[uo];
+  return 0.0f;
+}
+
+// Fragment table of the six products (scale factors as in njode_ode2.h: S = 2 log2 e on the
+// tanh layers, ik = 1 / (1 - p) on the consumers of dropout outputs), every value split into
+// its three bf16 pieces.
+template <class C>
+__global__ void k_pack_frags_x(const float* __restrict__ P, uint16_t* __restrict__ frag, float ik) {
+  using X = XF<C>;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;    // one (fragment, lane, j)
+  if (idx >= X::NALL * 64 * 8) return;
+  const int f = idx / 512, l = (idx >> 3) & 63, j = idx & 7, g = l >> 4, c = l & 15;
+  const float* Po = P + C::OFF_ODE;
+  using NL = typename C::Ode;
+  const float *W1 = Po + NL::woff(0), *b1 = Po + NL::boff(0), *W2 = Po + NL::woff(1),
+              *b2 = Po + NL::boff(1), *W3 = Po + NL::woff(2), *b3 = Po + NL::boff(2);
+  constexpr float S = C::ACT == ACT_TANH ? 2.8853900817779268f : 1.0f;
+  constexpr int Wd = X::W;
+  float v = 0.0f;
+  if (f < X::F2) {                 // W1: row = hidden unit, k = compact input entry
+    const int mt = f - X::F1, uo = X::hid_row_unit(mt, c), n = X::in_slot_entry(g, j);
+    if (uo < Wd && n < X::NIN) v = S * w1_entry<C>(W1, b1, uo, n);
+  } else if (f < X::F3) {          // W2: row = hidden unit, k = hidden unit / bias unit
+    const int mt = (f - X::F2) / X::KS1, ks = (f - X::F2) % X::KS1;
+    const int uo = X::hid_row_unit(mt, c), ui = X::hid_slot_unit(ks, g, j);
+    if (uo < Wd) v = ui < Wd ? S * ik * W2[uo * Wd + ui] : (ui == Wd ? S * b2[uo] : 0.0f);
+  } else if (f < X::NFWD) {        // W3: row = state unit (natural), k = hidden unit
+    const int ks = f - X::F3, uo = c, ui = X::hid_slot_unit(ks, g, j);
+    if (uo < X::H) v = ui < Wd ? ik * W3[uo * Wd + ui] : (ui == Wd ? b3[uo] : 0.0f);
+  } else if (f < X::B2) {          // W3^T: row = hidden unit, k-slot j < 4 = state unit 4g + j
+    const int mt = f - X::B3, ui = X::hid_row_unit(mt, c), uo = 4 * g + j;
+    if (ui < Wd && j < 4 && uo < X::H) v = ik * W3[uo * Wd + ui];
+  } else if (f < X::B1) {          // W2^T: row = hidden unit (input side), k = hidden unit (output side)
+    const int mt = (f - X::B2) / X::KS1, ks = (f - X::B2) % X::KS1;
+    const int ui = X::hid_row_unit(mt, c), uo = X::hid_slot_unit(ks, g, j);
+    if (ui < Wd && uo < Wd) v = ik * W2[uo * Wd + ui];
+  } else {                         // W1^T, state rows only: row = state unit, k = hidden unit
+    const int ks = f - X::B1, n = c, uo = X::hid_slot_unit(ks, g, j);
+    if (n < X::H && uo < Wd) v = W1[uo * C::ODE_IN + C::D + n];
+  }
+  uint16_t p[XNP];
+  split1(v, p);
+#pragma unroll
+  for (int q = 0; q < XNP; ++q) frag[((size_t)(f * XNP + q) * 64 + l) * 8 + j] = p[q];
+}
+
+// ---- per-lane vectors -------------------------------------------------------------------
+// packed B operand of one k-step: XNP pieces x 4 registers
+struct XOp {
+  u32x4 p[XNP];
+};
+// values (8 per lane) -> packed pieces
+NJ_DEV void pack8(const float (&v)[8], XOp& o) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t pc[XNP];
+    split2(v[2 * q], v[2 * q + 1], pc);
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) o.p[i][q] = pc[i];
+  }
+}
+// 4 values (slots j < 4; the other four slots are zero)
+NJ_DEV void pack4(const float (&v)[4], XOp& o) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    uint32_t pc[XNP];
+    split2(v[2 * q], v[2 * q + 1], pc);
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) o.p[i][q] = pc[i];
+  }
+#pragma unroll
+  for (int i = 0; i < XNP; ++i) { o.p[i][2] = 0; o.p[i][3] = 0; }
+}
+
+// A-fragment pieces of one (tile, k-step)
+struct XFrag {
+  u32x4 p[XNP];
+  NJ_DEV void load(const u32x4* frag, int f, int lane) {
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) p[i] = frag[(size_t)(f * XNP + i) * 64 + lane];
+  }
+};
+// acc += A x B over the six partial products (smallest first, so the large term is added last)
+NJ_DEV f32x4 xmma(const XFrag& A, const XOp& B, f32x4 acc) {
+#pragma unroll
+  for (int t = XNPROD - 1; t >= 0; --t) acc = mfma_bf16(A.p[XPI[t]], B.p[XPJ[t]], acc);
+  return acc;
+}
+
+// the part of the input that does not change along a segment (x, tau, one) is built once per
+// tile; per step only tanh(h) and t - tau are merged in
+template <class C> struct XIn {
+  using X = XF<C>;
+  float cst[8];       // constant entries of this lane's 8 slots (0 where the entry varies)
+  int kind[8];        // 0 constant, 1 state unit (tanh(h[r])), 2 tdiff, 3 tau + tdiff
+  NJ_DEV void init(int g, const float (&tx)[C::D], float tau) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= 4 && X::NIN <= 16) { cst[j] = 0.0f; kind[j] = 0; continue; }   // no second group
+      const int n = X::in_slot_entry(g, j);
+      const int e = n - X::H;
+      float v = 0.0f;
+      int k = 0;
+      if (n < X::H) k = 1;
+      else {
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) v = e == d ? tx[d] : v;
+        v = e == C::D ? tau : v;
+        v = e == X::NE - 1 ? 1.0f : v;
+        k = e == C::D + 1 ? 2 : (C::CURT && e == C::D + 2 ? 3 : 0);
+      }
+      cst[j] = v;
+      kind[j] = k;
+    }
+  }
+  NJ_DEV void build(const float (&th)[4], float tau, float tdiff, float (&v)[8]) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j >= 4 && X::NIN <= 16) { v[j] = 0.0f; continue; }
+      float x = cst[j];
+      if (j < 4) x = kind[j] == 1 ? th[j] : x;
+      x = kind[j] == 2 ? tdiff : x;
+      if constexpr (C::CURT) x = kind[j] == 3 ? tau + tdiff : x;
+      v[j] = x;
+    }
+  }
+};
+
+// hidden activations from the MT1 accumulator tiles: a (f32, 16 values per lane as
+// [ks][8]) with dropout applied (no scale: folded into the consumers' weights) and the
+// bias unit set to 1; optionally the derivative factor da (0 where dropped).
+template <class C, bool DROP, bool WANT_DA>
+NJ_DEV void x_hidden(const f32x4 (&acc)[XF<C>::MT1], float (&a)[XF<C>::KS1][8], float (&da)[XF<C>::KS1][8],
+                     uint32_t& st, uint32_t thr16, int g) {
+  using X = XF<C>;
+#pragma unroll
+  for (int ks = 0; ks < X::KS1; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const int mt = 2 * ks + (j >> 2), r = j & 3;
+      float v0 = act2_f<C::ACT>(acc[mt][r]), v1 = act2_f<C::ACT>(acc[mt][r + 1]);
+      float d0 = 0.0f, d1 = 0.0f;
+      if constexpr (WANT_DA) { d0 = dact_f<C::ACT>(v0); d1 = dact_f<C::ACT>(v1); }
+      if constexpr (DROP) {
+        const uint32_t w = xs32(st);
+        const bool k0 = (w & 0xffffu) >= thr16, k1 = (w >> 16) >= thr16;
+        v0 = k0 ? v0 : 0.0f;
+        v1 = k1 ? v1 : 0.0f;
+        if constexpr (WANT_DA) { d0 = k0 ? d0 : 0.0f; d1 = k1 ? d1 : 0.0f; }
+      }
+      a[ks][j] = v0;
+      a[ks][j + 1] = v1;
+      if constexpr (WANT_DA) { da[ks][j] = d0; da[ks][j + 1] = d1; }
+    }
+  // bias unit W: slot (ks, g, j) with 32 ks + 8 g + j == W
+  constexpr int KB = X::W / 32, GB = (X::W % 32) / 8, JB = X::W % 8;
+  a[KB][JB] = g == GB ? 1.0f : a[KB][JB];
+  if constexpr (WANT_DA) da[KB][JB] = g == GB ? 0.0f : da[KB][JB];
+}
+
+// Forward fragment providers: register-resident (168 VGPRs for the demo shape: two waves per
+// SIMD) or LDS-resident (one copy per block, re-read every step: leaves the waves ~110 VGPRs,
+// four waves per SIMD).
+template <class C> struct XFwdFragsReg {
+  using X = XF<C>;
+  XFrag A1[X::MT1], A2[X::MT1][X::KS1], A3[X::KS1];
+  NJ_DEV void init(const u32x4* frag, lfp, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt) {
+      A1[mt].load(frag, X::F1 + mt, lane);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) A2[mt][ks].load(frag, X::F2 + mt * X::KS1 + ks, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < X::KS1; ++ks) A3[ks].load(frag, X::F3 + ks, lane);
+  }
+  NJ_DEV void begin() {}
+  NJ_DEV XFrag a1(int mt) const { return A1[mt]; }
+  NJ_DEV XFrag a2(int mt, int ks) const { return A2[mt][ks]; }
+  NJ_DEV XFrag a3(int ks) const { return A3[ks]; }
+};
+typedef u32x4 __attribute__((address_space(3)))* lu4p;
+template <class C> struct XFwdFragsLds {
+  using X = XF<C>;
+  static constexpr int LDS_BYTES = X::NFWD * XNP * 1024;
+  lu4p base, cur;
+  // whole block copies the forward fragments into `lds`
+  NJ_DEV void init(const u32x4* frag, lfp lds, int lane) {
+    lu4p img = (lu4p)lds;
+    for (int i = threadIdx.x; i < X::NFWD * XNP * 64; i += blockDim.x) img[i] = frag[i];
+    __syncthreads();
+    base = img + lane;
+    cur = base;
+  }
+  // re-materialise the address once per step so the reads are not hoisted out of the time loop
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lu4p)(unsigned long long)v;
+  }
+  NJ_DEV XFrag get(int f) const {
+    XFrag r;
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) r.p[i] = cur[(f * XNP + i) * 64];
+    return r;
+  }
+  NJ_DEV XFrag a1(int mt) const { return get(X::F1 + mt); }
+  NJ_DEV XFrag a2(int mt, int ks) const { return get(X::F2 + mt * X::KS1 + ks); }
+  NJ_DEV XFrag a3(int ks) const { return get(X::F3 + ks); }
+};
+
+// B (x): Euler evolve of every item, one wave per tile of 16 items; worker `wave` of
+// `n_waves` walks the tiles [tile0, tile1) in snake order.  Same contract as ode_fwd_single.
+template <class C, bool DROP, bool TAIL, class FR>
+NJ_DEV void odex_fwd_single(const KArgs& a, lfp lds, int lane, int wave, int n_waves, int tile0, int tile1) {
+  using X = XF<C>;
+  const int g = lane >> 4, c = lane & 15;
+  FR F;
+  F.init((const u32x4*)a.fragx, lds, lane);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  const bool SAVE = !TAIL && a.save_traj != 0;
+  const int n_items = TAIL ? a.B : a.n_obs;
+  const int n_tiles = tile1 - tile0;
+  float* const trash = a.trash + lane * C::H;
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
+    const int jt = tile * 16 + c;
+    const bool valid = jt < n_items;
+    Item<C> it;
+    it.template load<TAIL>(a, jt, valid);
+    const float* h0 = it.h0(a);
+    float h[4];     // state units 4g .. 4g+3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      h[r] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
+    }
+    XIn<C> in;
+    in.init(g, it.tx, it.tau);
+    const int nmax = wave_max(it.n);
+    float dt_n = 0.0f, t_n = 0.0f;
+    long long base_n = 0;
+    if (nmax > 0) {
+      const int k0 = it.n > 0 ? it.kbeg : 0;
+      dt_n = it.n > 0 ? a.step_dt[k0] : 0.0f;
+      t_n = a.step_t[k0];
+      base_n = SAVE ? a.base_s[0] : 0;
+    }
+    for (int s = 0; s < nmax; ++s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      const float dt = dt_n, t = t_n;
+      const long long base = base_n;
+      if (s + 1 < nmax) {
+        const bool act_n = s + 1 < it.n;
+        const int kn = act_n ? it.kbeg + s + 1 : 0;
+        dt_n = act_n ? a.step_dt[kn] : 0.0f;
+        t_n = a.step_t[kn];
+        if (SAVE) base_n = a.base_s[s + 1];
+      }
+      if (SAVE) {
+        float* rec = active ? a.traj + (size_t)(base + jt) * C::H : trash;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 4 * g + r;
+          float* dst = u < C::H ? rec + u : trash;
+          *dst = h[r];
+        }
+      }
+      float th[4], v0[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) th[r] = tanh_f(h[r]);
+      in.build(th, it.tau, t - it.tau, v0);
+      XOp B0;
+      if constexpr (X::NIN <= 16) {
+        const float v4[4] = {v0[0], v0[1], v0[2], v0[3]};
+        pack4(v4, B0);
+      } else {
+        pack8(v0, B0);
+      }
+      uint32_t st = 0;
+      if constexpr (DROP) {
+        const unsigned long long gid = a.gid0 + it.b;
+        st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                        (uint32_t)k, NET_ODE);
+      }
+      f32x4 acc[X::MT1];
+      float av[X::KS1][8], dummy[X::KS1][8];
+      XOp B1[X::KS1];
+      F.begin();
+      // layer 1
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(F.a1(mt), B0, z);
+      x_hidden<C, DROP, false>(acc, av, dummy, st, a.dc.thr16, g);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(av[ks], B1[ks]);
+      // layer 2
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) {
+        f32x4 t = z;
+#pragma unroll
+        for (int ks = 0; ks < X::KS1; ++ks) t = xmma(F.a2(mt, ks), B1[ks], t);
+        acc[mt] = t;
+      }
+      x_hidden<C, DROP, false>(acc, av, dummy, st, a.dc.thr16, g);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(av[ks], B1[ks]);
+      // output layer: f (state units 4g .. 4g+3 in registers 0 .. 3)
+      f32x4 f = z;
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) f = xmma(F.a3(ks), B1[ks], f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = fmaf(dt, f[r], h[r]);   // dt = 0: inactive
+    }
+    float* out = valid ? (TAIL ? a.hT + (size_t)it.b * C::H : a.h_end + (size_t)it.r * C::H) : trash;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = h[r];
+    }
+  }
+}
+
+
+// ---- backward ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3)))* ls4p;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 __attribute__((address_space(3)))* lu2p;
+
+// LDS images for the dW products: [piece][chain row][unit], bf16.  A "wide" image holds a
+// hidden vector (64 unit columns), a "narrow" one the state / input vectors (16 NT0 columns).
+// Row strides are padded so the 16-byte row writes of 8 consecutive lanes fall in distinct
+// banks.  ds_read_b64_tr_b16 (block = 4 chain rows x 16 unit columns) hands lane i of a
+// 16-lane group column i of the four rows: with rows = chains that IS the A / B operand of a
+// product that sums over chains.
+template <class C> struct XImg {
+  using X = XF<C>;
+  static constexpr int WIDE_RS = 144, NARROW_RS = 16 * X::NT0 * 2 + 16;     // bytes per chain row
+  static constexpr int WIDE_PIECE = 16 * WIDE_RS, NARROW_PIECE = 16 * NARROW_RS;
+  static constexpr int WIDE_BYTES = XNP * WIDE_PIECE, NARROW_BYTES = XNP * NARROW_PIECE;
+  // per wave: one (delta, activation) pair at a time; the widest pair is two hidden vectors
+  static constexpr int WAVE_BYTES = 2 * WIDE_BYTES;
+  static constexpr int FRAG_BYTES = (X::NALL - X::NFWD) * XNP * 1024;        // transposed fragments
+  static constexpr int ZERO_BYTES = WIDE_BYTES;                              // what k-slots 16..31 read
+  static constexpr int NG = 1 * X::MT1 + X::MT1 * X::MT1 + X::MT1 * X::NT0;
+  static constexpr int RED_BYTES = 3 * NG * 64 * 16;
+  static constexpr int BODY_BYTES = FRAG_BYTES + ZERO_BYTES + 4 * WAVE_BYTES;
+  static constexpr int BYTES = BODY_BYTES > RED_BYTES ? BODY_BYTES : RED_BYTES;
+};
+
+// store a packed B operand (8 units 32 ks + 8 g .. of chain c) into a wide image
+NJ_DEV void ximg_put_wide(char __attribute__((address_space(3)))* img, int rs, int piece_bytes,
+                          const XOp& o, int ks, int g, int c) {
+#pragma unroll
+  for (int i = 0; i < XNP; ++i)
+    *(lu4p)(img + i * piece_bytes + c * rs + 64 * ks + 16 * g) = o.p[i];
+}
+// store 4 values (units / entries 4g .. 4g+3 of column group nt) into a narrow image
+NJ_DEV void ximg_put_narrow(char __attribute__((address_space(3)))* img, int rs, int piece_bytes,
+                            const XOp& o, int half, int nt, int g, int c) {
+#pragma unroll
+  for (int i = 0; i < XNP; ++i) {
+    const u32x2 v = {o.p[i][2 * half], o.p[i][2 * half + 1]};
+    *(lu2p)(img + i * piece_bytes + c * rs + 32 * nt + 8 * g) = v;
+  }
+}
+// operand of the 16 unit columns [16 t, 16 t + 16) summed over the wave's 16 chains:
+// lane (g, i): k-slots j = 0 .. 7 = chains 8 g + j (g < 2), zero for g >= 2 (the lane's
+// `base` then points into the zero image).
+NJ_DEV void ximg_get(const char __attribute__((address_space(3)))* base, int rs, int piece_bytes, int t,
+                     XOp& o) {
+#pragma unroll
+  for (int i = 0; i < XNP; ++i) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ls4p)(base + i * piece_bytes + 32 * t));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ls4p)(base + i * piece_bytes + 32 * t + 4 * rs));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    o.p[i] = u32x4{l2[0], l2[1], h2[0], h2[1]};
+  }
+}
+// acc += A x B (operand x operand)
+NJ_DEV f32x4 xmma_oo(const XOp& A, const XOp& B, f32x4 acc) {
+#pragma unroll
+  for (int t = XNPROD - 1; t >= 0; --t) acc = mfma_bf16(A.p[XPI[t]], B.p[XPJ[t]], acc);
+  return acc;
+}
+
+// transposed-product fragments, read from the block's LDS copy
+template <class C> struct XBwdLdsFrags {
+  using X = XF<C>;
+  lu4p base, cur;
+  static NJ_DEV void stage(lu4p img, const u32x4* frag) {
+    for (int i = threadIdx.x; i < (X::NALL - X::NFWD) * XNP * 64; i += blockDim.x)
+      img[i] = frag[X::NFWD * XNP * 64 + i];
+  }
+  NJ_DEV void init(lu4p img, int lane) { base = img + lane; cur = base; }
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lu4p)(unsigned long long)v;
+  }
+  NJ_DEV XFrag get(int f) const {
+    XFrag r;
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) r.p[i] = cur[((f - X::NFWD) * XNP + i) * 64];
+    return r;
+  }
+  NJ_DEV XFrag b3(int mt) const { return get(X::B3 + mt); }
+  NJ_DEV XFrag b2(int mt, int ks) const { return get(X::B2 + mt * X::KS1 + ks); }
+  NJ_DEV XFrag b1(int ks) const { return get(X::B1 + ks); }
+};
+
+// C (x): reverse Euler sweep of every segment + d loss / d ODE params.  One 256-thread block =
+// 4 independent workers (one wave per SIMD: the recompute fragments and the dW accumulator
+// tiles are register-resident, the transposed fragments live once per block in LDS); worker
+// `wave` of `n_waves` walks the tiles [tile0, tile1) in snake order; the block's workers sum
+// their gradient tiles into slab row `slab_row`.
+template <class C, bool DROP>
+NJ_DEV void odex_bwd_single(const KArgs& a, char __attribute__((address_space(3)))* lds, int wave,
+                            int n_waves, int tile0, int tile1, int slab_row) {
+  using X = XF<C>;
+  using I = XImg<C>;
+  using NL = typename C::Ode;
+  typedef char __attribute__((address_space(3)))* lbp;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  // ---- LDS: [transposed fragments][zero image][4 x (image A, image B)]
+  lu4p fimg = (lu4p)lds;
+  lbp zimg = lds + I::FRAG_BYTES;
+  lbp imgA = lds + I::FRAG_BYTES + I::ZERO_BYTES + wv * I::WAVE_BYTES, imgB = imgA + I::WIDE_BYTES;
+  XBwdLdsFrags<C>::stage(fimg, (const u32x4*)a.fragx);
+  for (int i = threadIdx.x; i < (I::ZERO_BYTES + 4 * I::WAVE_BYTES) / 4; i += 256)
+    ((float __attribute__((address_space(3)))*)zimg)[i] = 0.0f;
+  __syncthreads();
+  XBwdLdsFrags<C> FB;
+  FB.init(fimg, lane);
+  // recompute fragments in registers
+  XFrag A1[X::MT1], A2[X::MT1][X::KS1];
+#pragma unroll
+  for (int mt = 0; mt < X::MT1; ++mt) {
+    A1[mt].load((const u32x4*)a.fragx, X::F1 + mt, lane);
+#pragma unroll
+    for (int ks = 0; ks < X::KS1; ++ks) A2[mt][ks].load((const u32x4*)a.fragx, X::F2 + mt * X::KS1 + ks, lane);
+  }
+  // transposed-read bases: rows 8 g + q (g < 2) / the zero image (g >= 2), columns 4 p ..
+  const int q = c >> 2, pp = c & 3;
+  auto rd_base = [&](lbp img, int rs, bool zero_hi) -> lbp {
+    const int row = 8 * (g & 1) + q;
+    lbp real = img + row * rs + 8 * pp;
+    lbp zero = zimg + row * rs + 8 * pp;
+    return (zero_hi && g >= 2) ? zero : real;
+  };
+  const lbp rdA_wide = rd_base(imgA, I::WIDE_RS, true), rdB_wide = rd_base(imgB, I::WIDE_RS, false);
+  const lbp rdA_narrow = rd_base(imgA, I::NARROW_RS, true), rdB_narrow = rd_base(imgB, I::NARROW_RS, false);
+
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 G3[X::MT1], G2[X::MT1][X::MT1], G1[X::MT1][X::NT0];
+#pragma unroll
+  for (int i = 0; i < X::MT1; ++i) {
+    G3[i] = z;
+#pragma unroll
+    for (int n = 0; n < X::MT1; ++n) G2[i][n] = z;
+#pragma unroll
+    for (int n = 0; n < X::NT0; ++n) G1[i][n] = z;
+  }
+  float* const trash = a.trash + threadIdx.x * C::H;
+  const int n_tiles = tile1 - tile0;
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
+    const int jt = tile * 16 + c;
+    const bool valid = jt < a.n_obs;
+    Item<C> it;
+    it.template load<false>(a, jt, valid);
+    float lam[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
+      lam[r] = (valid && u < C::H) ? v : 0.0f;
+    }
+    XIn<C> in;
+    in.init(g, it.tx, it.tau);
+    const int nmax = wave_max(it.n);
+    auto fetch = [&](int s, float (&hh)[4], float& dtt, float& tt) {
+      const bool act = s < it.n;
+      const int kk = act ? it.kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + jt) * C::H : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 4 * g + r;
+        const float v = rec[u < C::H ? u : 0];
+        hh[r] = u < C::H ? v : 0.0f;
+      }
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[4] = {0.f, 0.f, 0.f, 0.f}, dt_n = 0.0f, t_n = 0.0f;
+    if (nmax > 0) fetch(nmax - 1, h_n, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      float h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = h_n[r];
+      const float dt = dt_n, t = t_n;
+      if (s > 0) fetch(s - 1, h_n, dt_n, t_n);
+      float th[4], v0[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) th[r] = tanh_f(h[r]);
+      in.build(th, it.tau, t - it.tau, v0);
+      XOp B0;
+      if constexpr (X::NIN <= 16) {
+        const float v4[4] = {v0[0], v0[1], v0[2], v0[3]};
+        pack4(v4, B0);
+      } else {
+        pack8(v0, B0);
+      }
+      uint32_t st = 0;
+      if constexpr (DROP) {
+        const unsigned long long gid = a.gid0 + it.b;
+        st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                        (uint32_t)k, NET_ODE);
+      }
+      FB.begin();
+      // ---- recompute the two hidden layers
+      f32x4 acc[X::MT1];
+      float av[X::KS1][8], da1[X::KS1][8], da2[X::KS1][8];
+      XOp B1[X::KS1], B2[X::KS1];
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(A1[mt], B0, z);
+      x_hidden<C, DROP, true>(acc, av, da1, st, a.dc.thr16, g);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(av[ks], B1[ks]);
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) {
+        f32x4 tt = z;
+#pragma unroll
+        for (int ks = 0; ks < X::KS1; ++ks) tt = xmma(A2[mt][ks], B1[ks], tt);
+        acc[mt] = tt;
+      }
+      x_hidden<C, DROP, true>(acc, av, da2, st, a.dc.thr16, g);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(av[ks], B2[ks]);
+
+      // ---- layer 3: delta3 = dt * lam (zero for inactive chains); dW3 = delta3 (x) [a2, 1]
+      float d3[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d3[r] = dt * lam[r];
+      XOp Bd3;
+      pack4(d3, Bd3);
+      ximg_put_narrow(imgA, I::NARROW_RS, I::NARROW_PIECE, Bd3, 0, 0, g, c);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(imgB, I::WIDE_RS, I::WIDE_PIECE, B2[ks], ks, g, c);
+      wave_lds_sync();
+      {
+        XOp Ad;
+        ximg_get(rdA_narrow, I::NARROW_RS, I::NARROW_PIECE, 0, Ad);
+#pragma unroll
+        for (int nt = 0; nt < X::MT1; ++nt) {
+          XOp Ba;
+          ximg_get(rdB_wide, I::WIDE_RS, I::WIDE_PIECE, nt, Ba);
+          G3[nt] = xmma_oo(Ad, Ba, G3[nt]);
+        }
+      }
+      // delta2 = (ik W3^T delta3) * act'(z2) * mask2
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(FB.b3(mt), Bd3, z);
+      float dv[X::KS1][8];
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[ks][j] = acc[2 * ks + (j >> 2)][j & 3] * da2[ks][j];
+      XOp Bd[X::KS1];
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(dv[ks], Bd[ks]);
+      wave_lds_sync();
+
+      // ---- layer 2: dW2 = delta2 (x) [a1, 1]
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) {
+        ximg_put_wide(imgA, I::WIDE_RS, I::WIDE_PIECE, Bd[ks], ks, g, c);
+        ximg_put_wide(imgB, I::WIDE_RS, I::WIDE_PIECE, B1[ks], ks, g, c);
+      }
+      wave_lds_sync();
+      {
+        XOp Ba[X::MT1];
+#pragma unroll
+        for (int nt = 0; nt < X::MT1; ++nt) ximg_get(rdB_wide, I::WIDE_RS, I::WIDE_PIECE, nt, Ba[nt]);
+#pragma unroll
+        for (int mt = 0; mt < X::MT1; ++mt) {
+          XOp Ad;
+          ximg_get(rdA_wide, I::WIDE_RS, I::WIDE_PIECE, mt, Ad);
+#pragma unroll
+          for (int nt = 0; nt < X::MT1; ++nt) G2[mt][nt] = xmma_oo(Ad, Ba[nt], G2[mt][nt]);
+        }
+      }
+      // delta1 = (ik W2^T delta2) * act'(z1) * mask1
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) {
+        f32x4 tt = z;
+#pragma unroll
+        for (int ks = 0; ks < X::KS1; ++ks) tt = xmma(FB.b2(mt, ks), Bd[ks], tt);
+        acc[mt] = tt;
+      }
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[ks][j] = acc[2 * ks + (j >> 2)][j & 3] * da1[ks][j];
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(dv[ks], Bd[ks]);
+      wave_lds_sync();
+
+      // ---- layer 1: dW1 = delta1 (x) [in0, 1]
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(imgA, I::WIDE_RS, I::WIDE_PIECE, Bd[ks], ks, g, c);
+#pragma unroll
+      for (int nt = 0; nt < X::NT0; ++nt) ximg_put_narrow(imgB, I::NARROW_RS, I::NARROW_PIECE, B0, nt, nt, g, c);
+      wave_lds_sync();
+      {
+        XOp Ba[X::NT0];
+#pragma unroll
+        for (int nt = 0; nt < X::NT0; ++nt) ximg_get(rdB_narrow, I::NARROW_RS, I::NARROW_PIECE, nt, Ba[nt]);
+#pragma unroll
+        for (int mt = 0; mt < X::MT1; ++mt) {
+          XOp Ad;
+          ximg_get(rdA_wide, I::WIDE_RS, I::WIDE_PIECE, mt, Ad);
+#pragma unroll
+          for (int nt = 0; nt < X::NT0; ++nt) G1[mt][nt] = xmma_oo(Ad, Ba[nt], G1[mt][nt]);
+        }
+      }
+      // adjoint of the state: lam += (W1^T delta1)[state rows] * (1 - tanh(h)^2)
+      f32x4 f = z;
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) f = xmma(FB.b1(ks), Bd[ks], f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dth = (4 * g + r) < C::H ? 1.0f - th[r] * th[r] : 0.0f;
+        lam[r] = fmaf(f[r], dth, lam[r]);
+      }
+      wave_lds_sync();
+    }
+    float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = lam[r];
+    }
+  }
+
+  // ---- flush: the block's four workers sum their tiles through LDS (fixed order) into ONE slab row
+  constexpr int NG = I::NG;
+  auto for_tiles = [&](auto fn) {
+    int i = 0;
+#pragma unroll
+    for (int nt = 0; nt < X::MT1; ++nt) fn(G3[nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < X::MT1; ++nt) fn(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < X::NT0; ++nt) fn(G1[mt][nt], i++);
+  };
+  __syncthreads();
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds;
+  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+  __syncthreads();
+  if (wv != 0) return;
+  for_tiles([&](f32x4& t, int i) {
+    t += red[(0 * NG + i) * 64 + lane];
+    t += red[(1 * NG + i) * 64 + lane];
+    t += red[(2 * NG + i) * 64 + lane];
+  });
+  const float ik = DROP ? a.dc.inv_keep : 1.0f;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+  constexpr int Wd = X::W;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    // G3: row = state unit 4g + r, column = hidden unit 16 nt + c
+    const int uh = 4 * g + r;
+    if (uh < C::H) {
+#pragma unroll
+      for (int nt = 0; nt < X::MT1; ++nt) {
+        const int ui = 16 * nt + c;
+        if (ui < Wd) W3[uh * Wd + ui] = ik * G3[nt][r];
+        else if (ui == Wd) b3[uh] = G3[nt][r];
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt) {
+      const int uo = 16 * mt + 4 * g + r;   // row = hidden unit
+      if (uo < Wd) {
+#pragma unroll
+        for (int nt = 0; nt < X::MT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < Wd) W2[uo * Wd + ui] = ik * G2[mt][nt][r];
+          else if (ui == Wd) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < X::NT0; ++nt) {
+          const int n = 16 * nt + c;        // compact input entry
+          if (n < X::H) W1[uo * C::ODE_IN + C::D + n] = G1[mt][nt][r];
+          else if (n - X::H < C::D) W1[uo * C::ODE_IN + (n - X::H)] = G1[mt][nt][r];
+          else if (n - X::H < X::NE - 1) W1[uo * C::ODE_IN + C::D + X::H + (n - X::H - C::D)] = G1[mt][nt][r];
+          else if (n - X::H == X::NE - 1) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+  }
+}
+
+
+// ---- backward, two waves per SIMD ---------------------------------------------------------
+// Same sweep with every fragment in LDS (one copy per 512-thread block) and ONE wide image
+// per wave: the activation image is read into registers (the B operands of all column tiles),
+// then the delta image takes its place and is consumed one row tile at a time.  A wave stays
+// under 256 registers, so eight waves share a CU and one wave's tanh / dropout / split work
+// runs beside another's MFMAs.
+template <class C, int NW> struct XImg2 {
+  using X = XF<C>;
+  // (XNP = 3: 136-byte rows keep eight waves + all fragments inside the 160 KB of a CU; the
+  // row writes then pair up two lanes per bank group)
+  static constexpr int WIDE_RS = XNP == 3 ? 136 : 144, NARROW_RS = 16 * X::NT0 * 2 + 16;
+  static constexpr int WIDE_PIECE = 16 * WIDE_RS, NARROW_PIECE = 16 * NARROW_RS;
+  static constexpr int WIDE_BYTES = XNP * WIDE_PIECE, NARROW_BYTES = XNP * NARROW_PIECE;
+  static constexpr int WAVE_BYTES = WIDE_BYTES + NARROW_BYTES;
+  static constexpr int FRAG_BYTES = X::NALL * XNP * 1024;
+  static constexpr int ZERO_BYTES = WIDE_BYTES;
+  static constexpr int NG = 1 * X::MT1 + X::MT1 * X::MT1 + X::MT1 * X::NT0;
+  static constexpr int RED_BYTES = (NW / 2) * NG * 64 * 16;       // two reduction rounds
+  static constexpr int BODY_BYTES = FRAG_BYTES + ZERO_BYTES + NW * WAVE_BYTES;
+  static constexpr int BYTES = BODY_BYTES > RED_BYTES ? BODY_BYTES : RED_BYTES;
+};
+template <class C> struct XAllLdsFrags {
+  using X = XF<C>;
+  lu4p base, cur;
+  static NJ_DEV void stage(lu4p img, const u32x4* frag) {
+    for (int i = threadIdx.x; i < X::NALL * XNP * 64; i += blockDim.x) img[i] = frag[i];
+  }
+  NJ_DEV void init(lu4p img, int lane) { base = img + lane; cur = base; }
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lu4p)(unsigned long long)v;
+  }
+  NJ_DEV XFrag get(int f) const {
+    XFrag r;
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) r.p[i] = cur[(f * XNP + i) * 64];
+    return r;
+  }
+  NJ_DEV XFrag a1(int mt) const { return get(X::F1 + mt); }
+  NJ_DEV XFrag a2(int mt, int ks) const { return get(X::F2 + mt * X::KS1 + ks); }
+  NJ_DEV XFrag b3(int mt) const { return get(X::B3 + mt); }
+  NJ_DEV XFrag b2(int mt, int ks) const { return get(X::B2 + mt * X::KS1 + ks); }
+  NJ_DEV XFrag b1(int ks) const { return get(X::B1 + ks); }
+};
+
+// block of NW waves = NW independent workers; worker `wave` of `n_waves` walks the tiles
+// [tile0, tile1) in snake order; one slab row per block
+template <class C, bool DROP, int NW>
+NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* lds, int wave, int n_waves,
+                        int tile0, int tile1, int slab_row) {
+  using X = XF<C>;
+  using I = XImg2<C, NW>;
+  using NL = typename C::Ode;
+  typedef char __attribute__((address_space(3)))* lbp;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  lu4p fimg = (lu4p)lds;
+  lbp zimg = lds + I::FRAG_BYTES;
+  lbp wide = lds + I::FRAG_BYTES + I::ZERO_BYTES + wv * I::WAVE_BYTES, narrow = wide + I::WIDE_BYTES;
+  XAllLdsFrags<C>::stage(fimg, (const u32x4*)a.fragx);
+  for (int i = threadIdx.x; i < (I::ZERO_BYTES + NW * I::WAVE_BYTES) / 4; i += NW * 64)
+    ((float __attribute__((address_space(3)))*)zimg)[i] = 0.0f;
+  __syncthreads();
+  XAllLdsFrags<C> F;
+  F.init(fimg, lane);
+  const int q = c >> 2, pp = c & 3;
+  auto rd_base = [&](lbp img, int rs, bool zero_hi) -> lbp {
+    const int row = 8 * (g & 1) + q;
+    return ((zero_hi && g >= 2) ? zimg : img) + row * rs + 8 * pp;
+  };
+  const lbp rdA_wide = rd_base(wide, I::WIDE_RS, true), rdB_wide = rd_base(wide, I::WIDE_RS, false);
+  const lbp rdA_narrow = rd_base(narrow, I::NARROW_RS, true), rdB_narrow = rd_base(narrow, I::NARROW_RS, false);
+
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 G3[X::MT1], G2[X::MT1][X::MT1], G1[X::MT1][X::NT0];
+#pragma unroll
+  for (int i = 0; i < X::MT1; ++i) {
+    G3[i] = z;
+#pragma unroll
+    for (int n = 0; n < X::MT1; ++n) G2[i][n] = z;
+#pragma unroll
+    for (int n = 0; n < X::NT0; ++n) G1[i][n] = z;
+  }
+  float* const trash = a.trash + threadIdx.x * C::H;
+  const int n_tiles = tile1 - tile0;
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
+    const int jt = tile * 16 + c;
+    const bool valid = jt < a.n_obs;
+    Item<C> it;
+    it.template load<false>(a, jt, valid);
+    float lam[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
+      lam[r] = (valid && u < C::H) ? v : 0.0f;
+    }
+    XIn<C> in;
+    in.init(g, it.tx, it.tau);
+    const int nmax = wave_max(it.n);
+    auto fetch = [&](int s, float (&hh)[4], float& dtt, float& tt) {
+      const bool act = s < it.n;
+      const int kk = act ? it.kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + jt) * C::H : 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 4 * g + r;
+        const float v = rec[u < C::H ? u : 0];
+        hh[r] = u < C::H ? v : 0.0f;
+      }
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[4] = {0.f, 0.f, 0.f, 0.f}, dt_n = 0.0f, t_n = 0.0f;
+    if (nmax > 0) fetch(nmax - 1, h_n, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      float h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[r] = h_n[r];
+      const float dt = dt_n, t = t_n;
+      if (s > 0) fetch(s - 1, h_n, dt_n, t_n);
+      float th[4], v0[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) th[r] = tanh_f(h[r]);
+      in.build(th, it.tau, t - it.tau, v0);
+      XOp B0;
+      if constexpr (X::NIN <= 16) {
+        const float v4[4] = {v0[0], v0[1], v0[2], v0[3]};
+        pack4(v4, B0);
+      } else {
+        pack8(v0, B0);
+      }
+      uint32_t st = 0;
+      if constexpr (DROP) {
+        const unsigned long long gid = a.gid0 + it.b;
+        st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                        (uint32_t)k, NET_ODE);
+      }
+      F.begin();
+      // delta3 = dt * lam (zero for inactive chains) and its image
+      float d3[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d3[r] = dt * lam[r];
+      XOp Bd3;
+      pack4(d3, Bd3);
+      ximg_put_narrow(narrow, I::NARROW_RS, I::NARROW_PIECE, Bd3, 0, 0, g, c);
+      // ---- recompute the two hidden layers
+      f32x4 acc[X::MT1];
+      float av[X::KS1][8], da1[X::KS1][8], da2[X::KS1][8];
+      XOp B1[X::KS1];
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(F.a1(mt), B0, z);
+      x_hidden<C, DROP, true>(acc, av, da1, st, a.dc.thr16, g);
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(av[ks], B1[ks]);
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) {
+        f32x4 tt = z;
+#pragma unroll
+        for (int ks = 0; ks < X::KS1; ++ks) tt = xmma(F.a2(mt, ks), B1[ks], tt);
+        acc[mt] = tt;
+      }
+      x_hidden<C, DROP, true>(acc, av, da2, st, a.dc.thr16, g);
+      {
+        XOp B2;
+#pragma unroll
+        for (int ks = 0; ks < X::KS1; ++ks) {
+          pack8(av[ks], B2);
+          ximg_put_wide(wide, I::WIDE_RS, I::WIDE_PIECE, B2, ks, g, c);
+        }
+      }
+      wave_lds_sync();
+      // ---- dW3 = delta3 (x) [a2, 1]
+      XOp Ba[X::MT1];
+      {
+        XOp Ad;
+        ximg_get(rdA_narrow, I::NARROW_RS, I::NARROW_PIECE, 0, Ad);
+#pragma unroll
+        for (int nt = 0; nt < X::MT1; ++nt) {
+          ximg_get(rdB_wide, I::WIDE_RS, I::WIDE_PIECE, nt, Ba[nt]);
+          G3[nt] = xmma_oo(Ad, Ba[nt], G3[nt]);
+        }
+      }
+      // delta2 = (ik W3^T delta3) * act'(z2) * mask2
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(F.b3(mt), Bd3, z);
+      float dv[X::KS1][8];
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[ks][j] = acc[2 * ks + (j >> 2)][j & 3] * da2[ks][j];
+      XOp Bd[X::KS1];
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(dv[ks], Bd[ks]);
+      wave_lds_sync();
+      // ---- dW2 = delta2 (x) [a1, 1]: a1 image -> registers, then the delta2 image in its place
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(wide, I::WIDE_RS, I::WIDE_PIECE, B1[ks], ks, g, c);
+      wave_lds_sync();
+#pragma unroll
+      for (int nt = 0; nt < X::MT1; ++nt) ximg_get(rdB_wide, I::WIDE_RS, I::WIDE_PIECE, nt, Ba[nt]);
+      wave_lds_sync();
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(wide, I::WIDE_RS, I::WIDE_PIECE, Bd[ks], ks, g, c);
+      wave_lds_sync();
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) {
+        XOp Ad;
+        ximg_get(rdA_wide, I::WIDE_RS, I::WIDE_PIECE, mt, Ad);
+#pragma unroll
+        for (int nt = 0; nt < X::MT1; ++nt) G2[mt][nt] = xmma_oo(Ad, Ba[nt], G2[mt][nt]);
+      }
+      // delta1 = (ik W2^T delta2) * act'(z1) * mask1
+#pragma unroll
+      for (int mt = 0; mt < X::MT1; ++mt) {
+        f32x4 tt = z;
+#pragma unroll
+        for (int ks = 0; ks < X::KS1; ++ks) tt = xmma(F.b2(mt, ks), Bd[ks], tt);
+        acc[mt] = tt;
+      }
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[ks][j] = acc[2 * ks + (j >> 2)][j & 3] * da1[ks][j];
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) pack8(dv[ks], Bd[ks]);
+      wave_lds_sync();
+      // ---- dW1 = delta1 (x) [in0, 1]
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(wide, I::WIDE_RS, I::WIDE_PIECE, Bd[ks], ks, g, c);
+#pragma unroll
+      for (int nt = 0; nt < X::NT0; ++nt) ximg_put_narrow(narrow, I::NARROW_RS, I::NARROW_PIECE, B0, nt, nt, g, c);
+      wave_lds_sync();
+      {
+        XOp Bi[X::NT0];
+#pragma unroll
+        for (int nt = 0; nt < X::NT0; ++nt) ximg_get(rdB_narrow, I::NARROW_RS, I::NARROW_PIECE, nt, Bi[nt]);
+#pragma unroll
+        for (int mt = 0; mt < X::MT1; ++mt) {
+          XOp Ad;
+          ximg_get(rdA_wide, I::WIDE_RS, I::WIDE_PIECE, mt, Ad);
+#pragma unroll
+          for (int nt = 0; nt < X::NT0; ++nt) G1[mt][nt] = xmma_oo(Ad, Bi[nt], G1[mt][nt]);
+        }
+      }
+      // adjoint of the state: lam += (W1^T delta1)[state rows] * (1 - tanh(h)^2)
+      f32x4 f = z;
+#pragma unroll
+      for (int ks = 0; ks < X::KS1; ++ks) f = xmma(F.b1(ks), Bd[ks], f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dth = (4 * g + r) < C::H ? 1.0f - th[r] * th[r] : 0.0f;
+        lam[r] = fmaf(f[r], dth, lam[r]);
+      }
+      wave_lds_sync();
+    }
+    float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u = 4 * g + r;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = lam[r];
+    }
+  }
+
+  // ---- flush: the block's workers sum their tiles through LDS (fixed order, two rounds for
+  // NW = 8) into ONE slab row
+  constexpr int NG = I::NG;
+  auto for_tiles = [&](auto fn) {
+    int i = 0;
+#pragma unroll
+    for (int nt = 0; nt < X::MT1; ++nt) fn(G3[nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < X::MT1; ++nt) fn(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < X::NT0; ++nt) fn(G1[mt][nt], i++);
+  };
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds;
+#pragma unroll
+  for (int half = NW / 2; half >= 1; half /= 2) {
+    __syncthreads();
+    if (wv >= half && wv < 2 * half) for_tiles([&](f32x4& t, int i) { red[((wv - half) * NG + i) * 64 + lane] = t; });
+    __syncthreads();
+    if (wv < half) for_tiles([&](f32x4& t, int i) { t += red[(wv * NG + i) * 64 + lane]; });
+  }
+  if (wv != 0) return;
+  const float ik = DROP ? a.dc.inv_keep : 1.0f;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+  constexpr int Wd = X::W;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int uh = 4 * g + r;
+    if (uh < C::H) {
+#pragma unroll
+      for (int nt = 0; nt < X::MT1; ++nt) {
+        const int ui = 16 * nt + c;
+        if (ui < Wd) W3[uh * Wd + ui] = ik * G3[nt][r];
+        else if (ui == Wd) b3[uh] = G3[nt][r];
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < X::MT1; ++mt) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < Wd) {
+#pragma unroll
+        for (int nt = 0; nt < X::MT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < Wd) W2[uo * Wd + ui] = ik * G2[mt][nt][r];
+          else if (ui == Wd) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < X::NT0; ++nt) {
+          const int n = 16 * nt + c;
+          if (n < X::H) W1[uo * C::ODE_IN + C::D + n] = G1[mt][nt][r];
+          else if (n - X::H < C::D) W1[uo * C::ODE_IN + (n - X::H)] = G1[mt][nt][r];
+          else if (n - X::H < X::NE - 1) W1[uo * C::ODE_IN + C::D + X::H + (n - X::H - C::D)] = G1[mt][nt][r];
+          else if (n - X::H == X::NE - 1) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace njode

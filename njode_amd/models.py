@@ -622,6 +622,8 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.distributed = distributed
         self.group = process_group
+        self.time_allreduce = False
+        self._allreduce_events = []
 
     def zero_grad(self):
         pass  # loss_and_grad overwrites the flat gradient
@@ -633,7 +635,14 @@ class FusedAdam:
             self.exp_avg = self.exp_avg.to(flat.device)
             self.exp_avg_sq = self.exp_avg_sq.to(flat.device)
         if self.distributed:
-            torch.distributed.all_reduce(grad, group=self.group)
+            if self.time_allreduce:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                torch.distributed.all_reduce(grad, group=self.group)
+                ev[1].record()
+                self._allreduce_events.append(ev)
+            else:
+                torch.distributed.all_reduce(grad, group=self.group)
         self.step_count += 1
         _lib.check(_lib.lib().njode_adam_step_f32(
             flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
@@ -641,12 +650,67 @@ class FusedAdam:
             self.eps, self.weight_decay, self.step_count, 1.0,
             torch.cuda.current_stream().cuda_stream))
 
+    def allreduce_ms(self):
+        """Mean device time of the gradient all-reduce since the last call (``time_allreduce``
+        must be set; synchronises)."""
+        if not self._allreduce_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._allreduce_events]
+        self._allreduce_events = []
+        return sum(ms) / len(ms)
+
+    # -- checkpoints: torch.optim.Adam's layout, so the reference's get_ckpt_model
+    # (optimizer.load_state_dict, models.py:63) reads a checkpoint of the fused loop and
+    # this class reads the reference's
+    def _param_index(self):
+        """[(offset, size, shape)] of the flat slices in ``model.parameters()`` order."""
+        m = self.model
+        m._ensure_flat()
+        by_id = {id(p): sl for sl, p in zip(m._param_slices, m._flat_params)}
+        return [by_id[id(p)] for p in m.parameters()]
+
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg': self.exp_avg.clone(),
-                'exp_avg_sq': self.exp_avg_sq.clone(), 'lr': self.lr, 'betas': self.betas,
-                'eps': self.eps, 'weight_decay': self.weight_decay}
+        idx = self._param_index()
+        state = {}
+        if self.step_count > 0:
+            for i, (off, n, shape) in enumerate(idx):
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': self.exp_avg[off:off + n].view(shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + n].view(shape).clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps,
+                 'weight_decay': self.weight_decay, 'amsgrad': False, 'maximize': False,
+                 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(idx)))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd['step'])
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        if 'param_groups' not in sd:      # round-1 private layout
+            self.step_count = int(sd['step'])
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            return
+        idx = self._param_index()
+        group = sd['param_groups'][0]
+        if len(sd['param_groups']) != 1 or len(group['params']) != len(idx):
+            raise ValueError('optimizer state has {} groups / {} parameters, the model has {} '
+                             'parameters'.format(len(sd['param_groups']), len(group['params']),
+                                                 len(idx)))
+        if group.get('amsgrad'):
+            raise ValueError('FusedAdam does not implement amsgrad')
+        self.lr, self.betas = group['lr'], tuple(group['betas'])
+        self.eps, self.weight_decay = group['eps'], group['weight_decay']
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for pos, key in enumerate(group['params']):
+            st = sd['state'].get(key)
+            if st is None:
+                continue
+            off, n, shape = idx[pos]
+            steps.add(int(float(st['step'])))
+            self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+        if len(steps) > 1:
+            raise ValueError('parameters with different step counts: {}'.format(sorted(steps)))
+        self.step_count = steps.pop() if steps else 0

@@ -62,6 +62,25 @@ def configure_model(model, global_batch, path_offset):
     model.dp_path_offset = int(path_offset)
 
 
+def empty_shard_step(model, fused=True):
+    """A rank whose shard of the global batch is empty (fewer paths than ranks in the last,
+    partial batch of an epoch) runs no kernels: its gradient contribution is zero, but it must
+    still take part in the gradient all-reduce and the optimizer step, or the other ranks
+    hang in the collective.  Returns the rank's (zero) loss contribution."""
+    if fused:
+        g = model.flat_grad()
+        g.zero_()
+        return torch.zeros((), dtype=torch.float32, device=g.device)
+    dev = None
+    for p in model.parameters():
+        dev = p.device
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        else:
+            p.grad.zero_()
+    return torch.zeros((), dtype=torch.float32, device=dev)
+
+
 def allreduce_flat_(flat, group=None):
     """In-place SUM all-reduce of a flat tensor (gradient, or [loss] for logging)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -156,7 +156,10 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             lo, hi = parallel.shard_range(len(idx), world, rank)
             parallel.configure_model(model, len(idx), lo)
             mine = idx[lo:hi]
-            if dev_ds is not None:
+            if len(mine) == 0:
+                d = dict(times=None, time_ptr=None, X=None, obs_idx=None, start_X=None,
+                         n_obs_ot=None)
+            elif dev_ds is not None:
                 d = dev_ds.collate(mine, func_names=functions or ())
             else:
                 b = data_utils.collate_arrays(stock_paths[mine], observed_dates[mine],
@@ -165,14 +168,18 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             args = (d['times'], d['time_ptr'], d['X'], d['obs_idx'], delta_t, T, d['start_X'],
                     d['n_obs_ot'])
             optimizer.zero_grad()
-            if fused:
+            if len(mine) == 0:
+                # more ranks than paths in this (last, partial) batch: contribute a zero
+                # gradient and still join the all-reduce and the optimizer step
+                loss = parallel.empty_shard_step(model, fused)
+            elif fused:
                 _, loss = model.loss_and_grad(*args)
             else:
                 _, loss = model(*args, return_path=False, get_loss=True)
                 loss.backward()
-                if world > 1:
-                    for p in model.parameters():
-                        parallel.allreduce_flat_(p.grad)
+            if not fused and world > 1:
+                for p in model.parameters():
+                    parallel.allreduce_flat_(p.grad)
             optimizer.step()
         torch.cuda.synchronize()
         train_time = time.time() - t0

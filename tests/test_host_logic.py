@@ -161,6 +161,56 @@ def test_checkpoint_roundtrip(tmp_path):
     assert torch.equal(m2.flat_parameters(), m.flat_parameters())
 
 
+def test_fused_adam_state_dict_is_torch_adam_layout(tmp_path):
+    """A checkpoint of the fused loop must load into torch.optim.Adam (what the reference's
+    get_ckpt_model does, models.py:63) and the reverse."""
+    m = _demo_model()
+    ref = torch.optim.Adam(m.parameters(), lr=2e-3, betas=(0.8, 0.95), eps=1e-7,
+                           weight_decay=0.0005)
+    torch.manual_seed(3)
+    before = m.flat_parameters().clone()
+    for _ in range(3):                      # three reference steps on random gradients
+        for p in m.parameters():
+            p.grad = torch.randn_like(p)
+        ref.step()
+    # reference -> fused
+    fused = models.FusedAdam(m)
+    fused.load_state_dict(ref.state_dict())
+    assert fused.step_count == 3 and fused.lr == 2e-3 and fused.betas == (0.8, 0.95)
+    assert fused.eps == 1e-7 and fused.weight_decay == 0.0005
+    idx = fused._param_index()
+    for i, p in enumerate(m.parameters()):
+        off, n, shape = idx[i]
+        assert torch.equal(fused.exp_avg[off:off + n].view(shape), ref.state[p]['exp_avg'])
+        assert torch.equal(fused.exp_avg_sq[off:off + n].view(shape), ref.state[p]['exp_avg_sq'])
+    # fused -> reference (through the checkpoint file, like train.py / get_ckpt_model)
+    models.save_checkpoint(m, fused, str(tmp_path), epoch=7)
+    m2 = _demo_model()
+    ref2 = torch.optim.Adam(m2.parameters())
+    models.get_ckpt_model(str(tmp_path), m2, ref2, 'cpu')
+    sd, sd2 = ref.state_dict(), ref2.state_dict()
+    assert sd2['param_groups'][0]['lr'] == 2e-3 and sd2['param_groups'][0]['betas'] == (0.8, 0.95)
+    assert sorted(sd2['state']) == sorted(sd['state'])
+    for k in sd['state']:
+        assert float(sd2['state'][k]['step']) == 3.0
+        assert torch.equal(sd2['state'][k]['exp_avg'], sd['state'][k]['exp_avg'])
+        assert torch.equal(sd2['state'][k]['exp_avg_sq'], sd['state'][k]['exp_avg_sq'])
+    # the two optimizers continue identically from there
+    g = [torch.randn_like(p) for p in m.parameters()]
+    for opt, mm in ((ref, m), (ref2, m2)):
+        for p, gi in zip(mm.parameters(), g):
+            p.grad = gi.clone()
+        opt.step()
+    assert torch.equal(m.flat_parameters(), m2.flat_parameters())
+    assert not torch.equal(m.flat_parameters(), before)
+    # a fresh optimizer has no per-parameter state, exactly like torch's
+    assert models.FusedAdam(_demo_model()).state_dict()['state'] == {}
+    # and FusedAdam reads its own checkpoints
+    f3 = models.FusedAdam(m2)
+    f3.load_state_dict(fused.state_dict())
+    assert f3.step_count == 3 and torch.equal(f3.exp_avg, fused.exp_avg)
+
+
 def test_library_loads_and_exports_declared_symbols():
     """Every function declared in include/*.h is exported by the built library (built by
     __graft_entry__.build(); no GPU needed to load it)."""

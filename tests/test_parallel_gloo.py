@@ -93,6 +93,57 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     assert a[0] == b[0]
 
 
+class _FlatModel:
+    """What parallel.empty_shard_step touches of the model (the flat gradient)."""
+
+    def __init__(self, n):
+        self._g = torch.full((n,), 7.0)        # stale gradient of the previous step
+
+    def flat_grad(self):
+        return self._g
+
+
+def _worker_empty_shard(rank, world, port, out_dir):
+    """Last partial batch of an epoch with fewer paths than ranks: the rank with
+    the empty shard must not run the kernels, must contribute zeros and must still join the
+    collective -- the loop of njode_amd/train.py, with the oracle as the compute."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    parallel.init_distributed('gloo')
+    g = Golden('g2_bs_grads_B64')
+    model = njode_oracle.make_oracle(g.cfg)
+    params = {k: v.clone().requires_grad_(True) for k, v in g.state_dict().items()}
+    hp = dict(data_utils.hyperparam_default, nb_paths=8)
+    paths, obs, nb_obs, meta = data_utils.create_dataset('BlackScholes', hp, seed=0)
+    idx = np.array([5])                                      # ONE path, two ranks
+    lo, hi = parallel.shard_range(len(idx), world, rank)
+    mine = idx[lo:hi]
+    dt, T = meta['dt'], meta['maturity']
+    n_flat = sum(p.numel() for p in params.values())
+    fm = _FlatModel(n_flat)
+    if len(mine) == 0:
+        loss = parallel.empty_shard_step(fm, fused=True)
+        assert float(loss) == 0.0
+        g_loc = fm.flat_grad()
+    else:
+        local = data_utils.collate_arrays(paths[mine], obs[mine], nb_obs[mine], dt)
+        _, g_loc = _flat_grad(model, params, local, dt, T, scale=(hi - lo) / len(idx))
+    parallel.allreduce_flat_(g_loc)
+    full = data_utils.collate_arrays(paths[idx], obs[idx], nb_obs[idx], dt)
+    _, g_full = _flat_grad(model, params, full, dt, T, scale=1.0)
+    assert float((g_loc - g_full).norm() / g_full.norm()) < 1e-6
+    np.save(os.path.join(out_dir, 'empty{}.npy'.format(rank)), np.array([hi - lo]))
+    dist.destroy_process_group()
+
+
+def test_rank_with_an_empty_shard_still_joins_the_allreduce(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_empty_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sizes = sorted(int(np.load(tmp_path / 'empty{}.npy'.format(r))[0]) for r in range(2))
+    assert sizes == [0, 1]
+
+
 def test_shard_ranges_partition_the_batch():
     for n in (1, 7, 64, 100, 20000):
         for world in (1, 2, 3, 8):
