@@ -10,8 +10,9 @@ step over all 20 000 paths of this rank as ONE batch:
     + [N > 1: RCCL all-reduce of the flat gradient, P = 10 071 floats]
     + Adam(lr 1e-3, weight_decay 5e-4) on the flat parameter vector.
 Inputs (start_X, X, obs_idx, n_obs_ot) are resident in HBM before the timed region.
-N > 1: every rank holds its own 20 000 paths (weak scaling), loss normalised by the
-global batch, one gradient all-reduce per step.
+N > 1: every rank holds its own 20 000 paths (weak scaling; --paths-per-gpu), or, with
+--global-paths G, the ranks share G paths (strong scaling, G / N each); the loss is
+normalised by the global batch, one gradient all-reduce per step.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -70,65 +71,109 @@ def flops_per_batch(b, n_hidden_units=50, d=1, H=10):
     return 3 * fwd, steps, n_obs
 
 
-def cpu_baseline(meta_dt, T, seconds_budget=28.0):
-    """The oracle (CPU restatement of the reference, plain PyTorch) timed on this
-    node's host cores on a bounded sample of the same workload: full training steps
-    (forward + backward + Adam, dropout 0.1) at the reference's shipped batch size 200
-    and on a 4 000-path batch, each at 8 intra-op threads (the survey container's
-    setting; more threads only add dispatch overhead on these tiny ops) and at 32.
-    The best paths/s is reported with the thread count that produced it."""
+def _cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+CPU_THREADS = 8   # intra-op threads of the CPU baseline (the survey container's core count)
+
+
+def cpu_baseline(meta_dt, T):
+    """The oracle (CPU restatement of the reference, plain PyTorch: kind "port") timed on
+    this node's host cores on a bounded sample of the same workload:
+    full training steps (forward + backward + Adam(lr 1e-3, wd 5e-4), dropout 0.1, train
+    mode) on seeded synthetic Black-Scholes batches, after 2 warm-up steps each:
+      * 20 timed steps at B = 100 (demo.py:81),
+      * 20 timed steps at B = 200 (the shipped models' batch size)  <- `value`,
+      * 2 timed steps at B = 4 000 (large-batch reference point),
+    all with a FIXED thread count (CPU_THREADS intra-op threads, or the host's core count
+    if smaller); no best-of."""
     from oracle import njode_oracle
     cfg = model_cfg(0.1)
     o = njode_oracle.make_oracle(cfg)
     params = {k: v.clone().requires_grad_(True) for k, v in o.init_params(0).items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-3, weight_decay=0.0005)
     default_threads = torch.get_num_threads()
+    threads = max(1, min(CPU_THREADS, os.cpu_count() or CPU_THREADS))
     results = {}
-    t_start = time.perf_counter()
-    plan = ((200, 8, 10), (4000, 8, 2), (4000, 32, 2), (200, 1, 4))
     try:
-        for bsz, threads, max_steps in plan:
-            if time.perf_counter() - t_start > seconds_budget:
-                break
-            torch.set_num_threads(min(threads, os.cpu_count() or threads))
+        torch.set_num_threads(threads)
+        for bsz, n_steps in ((100, 20), (200, 20), (4000, 2)):
             b, _ = make_batch(bsz, seed=1234)
-            njode_oracle.train_step(o, params, opt, b, meta_dt, T)      # warm-up
-            n, t0 = 0, time.perf_counter()
-            while n < max_steps and time.perf_counter() - t_start < seconds_budget:
+            for _ in range(2):
+                njode_oracle.train_step(o, params, opt, b, meta_dt, T)      # warm-up
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
                 njode_oracle.train_step(o, params, opt, b, meta_dt, T)
-                n += 1
             dt = time.perf_counter() - t0
-            if n:
-                results[(bsz, threads)] = (bsz * n / dt, n)
+            results[bsz] = (bsz * n_steps / dt, n_steps, 1e3 * dt / n_steps)
     finally:
         torch.set_num_threads(default_threads)
-    best = max(results, key=lambda k: results[k][0])
-    sample = '; '.join('{} steps B={} threads={} -> {:.0f} paths/s'.format(
-        results[k][1], k[0], k[1], results[k][0]) for k in sorted(results))
-    return {'value': round(results[best][0], 1), 'unit': 'paths/s', 'cores': best[1],
+    sample = '; '.join('{} steps at B={}: {:.0f} paths/s ({:.1f} ms/step)'.format(
+        results[k][1], k, results[k][0], results[k][2]) for k in sorted(results))
+    return {'value': round(results[200][0], 1), 'unit': 'paths/s', 'cores': threads,
             'kind': 'port',
-            'sample': 'oracle train step (fwd+bwd+Adam, dropout 0.1) on synthetic '
-                      'Black-Scholes batches: ' + sample,
-            'host_cpu_count': os.cpu_count()}
+            'sample': 'oracle train step (fwd+bwd+Adam, dropout 0.1, train mode) on seeded '
+                      'synthetic Black-Scholes batches, {} intra-op threads, 2 warm-up steps '
+                      'each: {}; value = the B=200 line'.format(threads, sample),
+            'by_batch': {str(k): round(v[0], 1) for k, v in results.items()},
+            'cpu_model': _cpu_model_name(), 'host_cpu_count': os.cpu_count()}
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate passes, tools/summarize_pmc.py; KiB units).  The
-    gfx950 x2 FETCH_SIZE correction applies to wide coalesced streams; this kernel's
-    accesses are 4-byte, so the raw counters are reported (MI355X_MICROARCH.md, HBM)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*final_pmc_summary.json')))
-    if not files:
-        return None, None
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_final_pmc_summary.json')
+
+
+def measured_traffic(kernel, n_paths, dropout):
+    """HBM bytes per launch of `kernel` as MEASURED on this build: profiles/
+    r02_final_pmc_summary.json is written by tools/summarize_pmc.py from `rocprofv3 --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `python bench.py` (recipe: profiles/README.md),
+    and records the workload it was taken on.  Returned only when that workload is the one
+    being benchmarked, else None (a counter cannot be collected inside this process).
+    Units: rocprofv3 reports KiB; the kernel's accesses are 4-byte, i.e. outside the
+    calibrated (16 B / lane) regime of MI355X_MICROARCH.md's x2 FETCH_SIZE correction, so the
+    raw sum is reported."""
     try:
-        with open(files[-1]) as f:
-            d = json.load(f).get(kernel, {})
-        if d.get('FETCH_SIZE') is not None and d.get('WRITE_SIZE') is not None:
-            return int((d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024), d.get('traffic_source')
+        with open(PMC_SUMMARY) as f:
+            d = json.load(f)
     except (OSError, ValueError):
-        pass
-    return None, None
+        return None, None
+    wl = d.get('_workload', {})
+    if wl.get('paths_per_gpu') != n_paths or abs(wl.get('dropout', -1) - dropout) > 1e-12:
+        return None, None
+    k = d.get(kernel, {})
+    if k.get('FETCH_SIZE') is None or k.get('WRITE_SIZE') is None:
+        return None, None
+    return int((k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024), wl.get('command')
+
+
+def small_batch_ms(model, opt, dev, dt, T, sizes=(100, 200), steps=30):
+    """ms per training step at the reference's own batch sizes (demo.py:81 trains at B = 100,
+    the shipped models at 200), same model / optimizer, inputs resident: an extra, outside
+    the timed region of `value`."""
+    out = {}
+    for bsz in sizes:
+        b, _ = make_batch(bsz, seed=4321)
+        args = (b['times'], b['time_ptr'], b['X'].to(dev), b['obs_idx'].to(dev, torch.int32), dt, T,
+                b['start_X'].to(dev), b['n_obs_ot'].to(dev, torch.int32))
+        model.dp_global_batch, model.dp_path_offset = bsz, 0
+        for _ in range(5):
+            model.loss_and_grad(*args)
+            opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.loss_and_grad(*args)
+            opt.step()
+        torch.cuda.synchronize()
+        out[bsz] = 1e3 * (time.perf_counter() - t0) / steps
+    return out
 
 
 def main():
@@ -136,10 +181,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--paths-per-gpu', type=int, default=20000)
+    ap.add_argument('--paths-per-gpu', type=int, default=20000,
+                    help='weak scaling: every rank holds this many paths (default)')
+    ap.add_argument('--global-paths', type=int, default=0,
+                    help='strong scaling: the ranks share this many paths (e.g. 1000000 on 8 GPUs)')
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-small-batch', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -157,23 +206,31 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    backend = None
     if distributed:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = 'gloo' if share else 'nccl'
         if share:
             torch.distributed.init_process_group('gloo')
         else:
             torch.distributed.init_process_group('nccl', device_id=dev)
 
-    from njode_amd import _lib, models
+    from njode_amd import _lib, models, parallel
 
-    B = args.paths_per_gpu
+    strong = args.global_paths > 0
+    if strong:
+        lo, hi = parallel.shard_range(args.global_paths, world, rank)
+        B, path_offset, global_batch = hi - lo, lo, args.global_paths
+    else:
+        B = args.paths_per_gpu
+        path_offset, global_batch = B * rank, B * world
     b, meta = make_batch(B, seed=rank)
     dt, T = meta['dt'], meta['maturity']
     torch.manual_seed(0)                       # identical init on every rank
     with contextlib.redirect_stdout(sys.stderr):   # the ctor prints like the reference's does
         model = models.NJODE(**model_cfg(args.dropout)).to(dev).train()
-    model.dp_global_batch = B * world
-    model.dp_path_offset = B * rank
+    model.dp_global_batch = global_batch
+    model.dp_path_offset = path_offset
     opt = models.FusedAdam(model, lr=1e-3, weight_decay=0.0005, distributed=distributed)
     # inputs resident in HBM before the timed region
     X, start_X = b['X'].to(dev), b['start_X'].to(dev)
@@ -198,39 +255,55 @@ def main():
     sync()
     if timing:
         _lib.profile_enable(True)
+    opt.time_allreduce = distributed        # HIP events around the collective (device time)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    opt.time_allreduce = False
+    allreduce_ms = opt.allreduce_ms()
     kern = {}
     if timing:
         _lib.profile_enable(False)
         kern = _lib.profile_read()
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed_local], device=dev, dtype=torch.float64)
+    per_rank = [elapsed_local]
     if distributed:
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(gathered, t)
+        per_rank = [float(x) for x in gathered]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t)
     final_loss = float(loss)
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
-        value = B * world * args.steps / elapsed
+        value = global_batch * args.steps / elapsed
         flops, euler_steps, n_obs = flops_per_batch(b)
         out = {
             'metric': 'paths/sec (training step) on 20k Black-Scholes, 100 steps',
             'value': round(value, 1), 'unit': 'paths/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BlackScholes {} paths/GPU x 100 grid steps as one batch, '
-                                   'hidden_size=10, 3x(50,50) tanh nets, dropout {}, train step '
-                                   '= plan+fwd+bwd+{}Adam'.format(
-                                       B, args.dropout, 'RCCL all-reduce+' if distributed else ''),
-                       'global_batch': B * world, 'n_obs_rows': n_obs,
+            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'BlackScholes {} x 100 grid steps, every rank\'s paths as one '
+                                   'batch, hidden_size=10, 3x(50,50) tanh nets, dropout {}, train '
+                                   'step = plan+fwd+bwd+{}Adam'.format(
+                                       '{} paths shared by {} GPU(s)'.format(global_batch, world)
+                                       if strong else '{} paths/GPU'.format(B),
+                                       args.dropout, 'RCCL all-reduce+' if distributed else ''),
+                       'global_batch': global_batch, 'paths_rank0': B, 'n_obs_rows': n_obs,
                        'euler_steps_per_batch': euler_steps, 'params': 10071,
                        'parallelism': 'dp{}'.format(world)},
             'final_loss': final_loss,
         }
+        if distributed:
+            out['rccl_world'] = torch.distributed.get_world_size()
+            out['collective_backend'] = backend + (' (RCCL)' if backend == 'nccl' else '')
+            out['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 5)
+            out['allreduce_floats'] = int(model.flat_grad().numel())
+            out['ms_per_step_by_rank'] = [round(1e3 * x / args.steps, 4) for x in per_rank]
         if kern:
             per = {k: round(v[1] / max(v[0], 1), 5) for k, v in kern.items()}
             out['kernel_ms'] = per
@@ -238,25 +311,39 @@ def main():
             dom_ms = kern[dom][1] / max(kern[dom][0], 1)
             H, W, IN0 = 10, 50, 13
             # ALGORITHMIC work of one launch of the ODE kernels, per
-            # Euler step of one path, biases counted as one MAC per output:
-            #   forward : (IN0+1) W + (W+1) W + (W+1) H                      = 3 760 MAC
-            #   backward: recompute L1+L2 3 250 + transposed products 3 500
-            #             + weight-gradient outer products 3 760             = 10 510 MAC
-            macs = {'k_ode_bwd_mixed': 10510, 'k_ode_bwd_mfma': 10510, 'k_ode_bwd_items': 10510 + 510,
-                    'k_ode_fwd_mfma': 3760, 'k_ode_fwd_items': 3760}.get(dom)
+            # Euler step of one path.  STRICT: the network is 13.50 + 50.50 +
+            # 50.10 = 3 650 MAC forward, its exact backward 2x that = 7 300 MAC = 14 600 flop.
+            # WITH RECOMPUTE (what the backward kernel executes of useful work, biases as one
+            # MAC per output): recompute L1+L2 3 250 + transposed products 3 500 + weight-gradient
+            # outer products 3 760 = 10 510 MAC.  Tile padding (50->64, 10->16) is never counted.
+            strict = {'k_ode_bwd_mixed': 7300, 'k_ode_bwd_mfma': 7300, 'k_ode_bwd_items': 7300,
+                      'k_ode_fwd_mixed': 3650, 'k_ode_fwd_mfma': 3650, 'k_ode_fwd_items': 3650}.get(dom)
+            executed = {'k_ode_bwd_mixed': 10510, 'k_ode_bwd_mfma': 10510,
+                        'k_ode_bwd_items': 10510 + 510, 'k_ode_fwd_mixed': 3760,
+                        'k_ode_fwd_mfma': 3760, 'k_ode_fwd_items': 3760}.get(dom)
             bytes_ = euler_steps * H * 4 + n_obs * (2 * H * 4 + 32)
-            if macs is not None:
-                tf_k = 2.0 * macs * euler_steps / (dom_ms * 1e-3) / 1e12
+            if strict is not None:
+                tf_s = 2.0 * strict * euler_steps / (dom_ms * 1e-3) / 1e12
+                tf_e = 2.0 * executed * euler_steps / (dom_ms * 1e-3) / 1e12
+                traffic, traffic_src = measured_traffic(dom, B, args.dropout)
                 out['roofline'] = {
-                    'bound': 'mfma', 'kernel': dom, 'achieved': round(tf_k, 3),
+                    'bound': 'mfma', 'kernel': dom, 'achieved': round(tf_s, 3),
                     'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                    'frac': round(tf_k / FP32_MFMA_PEAK_TF, 5),
-                    'traffic': measured_traffic(dom)[0],
-                    'traffic_source': measured_traffic(dom)[1],
+                    'frac': round(tf_s / FP32_MFMA_PEAK_TF, 5),
+                    'frac_strict': round(tf_s / FP32_MFMA_PEAK_TF, 5),
+                    'frac_with_recompute': round(tf_e / FP32_MFMA_PEAK_TF, 5),
+                    'achieved_with_recompute': round(tf_e, 3),
+                    'traffic': traffic, 'traffic_source': traffic_src,
                     'kernel_ms': round(dom_ms, 5),
-                    'algorithmic_flops': int(2 * macs * euler_steps),
-                    'note': 'f32 MFMA (v_mfma_f32_16x16x4_f32) dense peak = f32 vector peak; '
-                            'useful FLOPs only (tile padding 50->64 not counted)'}
+                    'algorithmic_flops': int(2 * strict * euler_steps),
+                    'executed_useful_flops': int(2 * executed * euler_steps),
+                    'note': 'achieved / frac = STRICT algorithmic work (SURVEY 8d: 14 600 flop per '
+                            'Euler step of the backward, 7 300 forward); frac_with_recompute also '
+                            'counts the checkpoint recompute and the bias MACs the kernel really '
+                            'executes.  Peak = dense f32 MFMA = f32 vector peak; on gfx950 '
+                            'v_mfma_f32_16x16x4_f32 and the VALU share ONE pipe (measured: '
+                            'profiles/r02_pipe_ubench.jsonl), so the tanh / dropout / delta VALU '
+                            'work of the kernel spends the same peak (DESIGN.md section 5)'}
                 gbs = bytes_ / (dom_ms * 1e-3) / 1e9
                 out['hbm_roofline'] = {
                     'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 3),
@@ -269,6 +356,12 @@ def main():
                                  'unit': 'TFLOP/s', 'frac': round(tf / FP32_MFMA_PEAK_TF, 5),
                                  'useful_flops_per_step': int(flops),
                                  'note': 'whole step incl. plan, reductions, Adam, launches'}
+        if world == 1 and not args.no_small_batch:
+            sb = small_batch_ms(model, opt, dev, dt, T)
+            out['b100_ms'] = round(sb[100], 4)
+            out['b200_ms'] = round(sb[200], 4)
+            out['b100_paths_per_s'] = round(100 / (sb[100] * 1e-3), 1)
+            out['b200_paths_per_s'] = round(200 / (sb[200] * 1e-3), 1)
         if world == 1 and not args.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):
                 out['cpu_baseline'] = cpu_baseline(dt, T)

@@ -35,6 +35,12 @@ CONFIGS = [
     (41, 41, 41, 2, 50, TANH, 1, 0, 1, 0),  # PhysioNet shape, reference setting (H=41 residual)
     (41, 50, 41, 2, 50, TANH, 1, 0, 0, 0),  # PhysioNet shape, BASELINE config 5 wording (H=50)
     (1, 10, 1, 2, 50, TANH, 0, 0, 1, 1),    # use_rnn=True: GRU jump (models.py:202-217)
+    # network widths of the reference's convergence study that fit the matrix-core kernels
+    # (parallel_train.py:304-305: 10, 20, 40, 80, 160, 320; wider ones: NJODE_EXTRA_CONFIGS /
+    # compile on first use, see models.NJODE._get_dims)
+    (1, 10, 1, 2, 10, TANH, 0, 0, 1, 0),
+    (1, 10, 1, 2, 20, TANH, 0, 0, 1, 0),
+    (1, 10, 1, 2, 40, TANH, 0, 0, 1, 0),
 ]
 
 

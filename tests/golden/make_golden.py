@@ -14,6 +14,14 @@ Cases:
   g5_masked               PhysioNet-shaped masked batch, loss/path/grads
   g6_*                    variants: input_current_t, easy loss, no residual,
                           func_appl_X, use_rnn, sparse times (B=5), empty slice
+  g7 (round 2; `python tests/golden/make_golden.py g7` makes only these):
+  g5_full                 PhysioNet-shaped masked batch at FULL length: B = 8, d = H = 41,
+                          3 000 Euler steps (physionet_train.py:93,326-353), loss / path / grads
+  g6_w{10,40}             network widths of the convergence study (parallel_train.py:304-305)
+  ds_ref_BS/              a dataset directory written by the reference's create_dataset
+                          (data_utils.py:56-105): data.npy + metadata.txt, 12 paths
+  g8_physionet_eval       physionet_train.evaluate_model protocol (:411-510) on a synthetic
+                          stand-in: observe the first half, predict the second half
 """
 import contextlib
 import copy
@@ -287,7 +295,132 @@ def g6():
     save('g6_offgrid_dt', cfg, arrays)
 
 
+def g7():
+    # ---- config 5 at its real length: 3 000 Euler steps, 30..100 observation times per path
+    b = synthetic_physionet.make_batch(batch_size=8, n_grid=3000, n_obs_range=(30, 100), seed=1)
+    cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN,
+               readout_nn=NN, enc_nn=NN, use_rnn=False, bias=True,
+               dropout_rate=0.0, options={'masked': True})
+    model = build(cfg)
+    arrays = {**sd_arrays(model), **batch_arrays(b, with_M=True),
+              'delta_t': b['delta_t'], 'T': b['T']}
+    out = eval_outputs(model, b, b['delta_t'], b['T'], M=b['M'])
+    out.pop('path_h')
+    n_rows = out['path_y'].shape[0]
+    rows = np.unique(np.concatenate([np.arange(0, n_rows, 40), [n_rows - 1]]))
+    out['path_rows'] = rows.astype(np.int64)          # the stored rows of the path
+    out['path_y'] = out['path_y'][rows]
+    arrays.update(out)
+    arrays.update(grad_outputs(model, b, b['delta_t'], b['T'], M=b['M']))
+    save('g5_full', cfg, arrays)
+
+    # ---- widths of the convergence study that the matrix-core kernels cover
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    dt, T = hp['dt'], hp['maturity']
+    for w in (10, 40):
+        nn = ((w, 'tanh'), (w, 'tanh'))
+        cfg = dict(demo_cfg(dropout=0.0), ode_nn=nn, enc_nn=nn, readout_nn=nn)
+        model = build(cfg)
+        b = ref_collate(paths, obs, nb_obs, dt, range(20))   # the study's batch size
+        arrays = {**sd_arrays(model), **batch_arrays(b), 'delta_t': dt, 'T': T}
+        arrays.update(eval_outputs(model, b, dt, T))
+        arrays.update(grad_outputs(model, b, dt, T))
+        save('g6_w{}'.format(w), cfg, arrays)
+
+    # ---- a dataset directory exactly as the reference writes it (f2)
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    try:
+        os.makedirs(os.path.join(tmp, 'a', 'b'))
+        os.chdir(os.path.join(tmp, 'a', 'b'))            # the reference writes to ../data/...
+        old = ref_data.training_data_path
+        ref_data.training_data_path = os.path.join(tmp, 'data', 'training_data') + '/'
+        os.makedirs(ref_data.training_data_path)
+        hp2 = copy.deepcopy(ref_data.hyperparam_default)
+        hp2['nb_paths'] = 12
+        path, time_id = quiet(ref_data.create_dataset, 'BlackScholes', hp2, seed=0)
+        dst = os.path.join(HERE, 'ds_ref_BS')
+        if os.path.exists(dst):
+            shutil.rmtree(dst)
+        shutil.copytree(path, dst)
+        ref_data.training_data_path = old
+        print('ds_ref_BS/ <-', path, os.listdir(dst))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+
+
+def _reference_physionet_functions():
+    """evaluate_model / get_comparison_times_ind of NJODE/physionet_train.py, executed from the
+    reference's own source (the module itself cannot be imported here: its imports need
+    torchvision / telegram)."""
+    import ast
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'likelihood_eval_LODE', '/root/reference/latent_ODE/likelihood_eval_LODE.py')
+    sys.path.insert(0, '/root/reference/latent_ODE')
+    sys.path.insert(0, '/root/reference')
+    try:
+        likelihood_eval = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(likelihood_eval)
+    except Exception as e:      # its helper imports are not available: restate the two callees
+        print('   (likelihood_eval_LODE not importable: {}; using its two functions only)'.format(e))
+        src = open('/root/reference/latent_ODE/likelihood_eval_LODE.py').read()
+        tree = ast.parse(src)
+        keep = [n for n in tree.body if isinstance(n, ast.FunctionDef)
+                and n.name in ('compute_masked_likelihood', 'mse')]
+        ns = {'torch': torch, 'nn': torch.nn, 'np': np, 'get_device': lambda t: t.device}
+        exec(compile(ast.Module(keep, []), 'likelihood_eval_LODE.py', 'exec'), ns)
+        import types
+        likelihood_eval = types.SimpleNamespace(**{k: ns[k] for k in ('compute_masked_likelihood', 'mse')})
+    src = open('/root/reference/NJODE/physionet_train.py').read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef)
+            and n.name in ('evaluate_model', 'get_comparison_times_ind')]
+    if not hasattr(np, 'int'):
+        np.int = int            # the reference predates numpy 1.24
+    ns = {'np': np, 'torch': torch, 'likelihood_eval': likelihood_eval}
+    exec(compile(ast.Module(keep, []), 'physionet_train.py', 'exec'), ns)
+    return ns['evaluate_model'], ns['get_comparison_times_ind']
+
+
+def g8():
+    from njode_amd import physionet_eval
+    evaluate_model, get_ind = _reference_physionet_functions()
+    cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN,
+               readout_nn=NN, enc_nn=NN, use_rnn=False, bias=True,
+               dropout_rate=0.0, options={'masked': True})
+    model = build(cfg)
+    batches = [physionet_eval.make_eval_batch(batch_size=6, n_grid=240, n_obs_range=(6, 16), seed=s)
+               for s in (3, 4)]
+    dt, T = batches[0]['delta_t'], batches[0]['T']
+    loss_val, mse_val, mse_val_2 = quiet(evaluate_model, model, batches, 'cpu', {}, dt, T)
+    arrays = {**sd_arrays(model), 'delta_t': dt, 'T': T, 'n_batches': len(batches),
+              'loss_val': np.float64(loss_val), 'mse_val': np.float64(mse_val),
+              'mse_val_2': np.float64(mse_val_2)}
+    for i, b in enumerate(batches):
+        for k in ('times', 'time_ptr', 'times_val', 'vals_val', 'mask_val'):
+            arrays['b{}/{}'.format(i, k)] = np.asarray(b[k])
+        for k in ('X', 'M', 'obs_idx'):
+            arrays['b{}/{}'.format(i, k)] = b[k].numpy()
+        arrays['b{}/batch_size'.format(i)] = b['batch_size']
+        # comparison indices of the reference on this batch's prediction grid
+        model.eval()
+        with torch.no_grad():
+            n_obs_ot = torch.tensor(np.bincount(b['obs_idx'].numpy(), minlength=b['batch_size']))
+            _, _, path_t, _, _ = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt, T,
+                                       torch.zeros(b['batch_size'], 41), n_obs_ot, until_T=True,
+                                       return_path=True, get_loss=True, M=b['M'])
+        arrays['b{}/path_t'.format(i)] = np.asarray(path_t, dtype=np.float64)
+        arrays['b{}/cmp_ind'.format(i)] = np.asarray(get_ind(path_t, b['times_val']), dtype=np.int64)
+    print('    physionet eval protocol:', loss_val, mse_val, mse_val_2)
+    save('g8_physionet_eval', cfg, arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    for fn in (g1, g2, g3, g4, g5, g6):
-        fn()
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    for name in which:
+        globals()[name]()

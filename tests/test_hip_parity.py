@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from golden_util import Golden, all_model_cases
-from hip_util import (ATOL, GRAD_REL_L2, LOSS_RTOL, RTOL, bs_batch, demo_cfg, grads_by_name,
+from hip_util import (ATOL, GRAD_REL_L2, LOSS_RTOL, RTOL, RTOL_LONG, bs_batch, demo_cfg, grads_by_name,
                       hip_forward, hip_model, oracle_forward, rel_l2, to_dev)
 from njode_amd import _lib, data_utils, models, stock_model
 
@@ -38,8 +38,12 @@ def test_eval_path_matches_reference(name):
     # masked mode feeds predictions back as inputs; |y| reaches 15 there, so the
     # absolute floor is scaled with the data (2e-5 ~ 1.4e-6 relative to max |y|)
     atol = 2e-5 if name.startswith('g5_') else ATOL
-    np.testing.assert_allclose(path_y.cpu().numpy(), g['path_y'], atol=atol, rtol=RTOL)
-    np.testing.assert_allclose(hT.cpu().numpy(), g['hT'], atol=atol, rtol=RTOL)
+    # config 5 at its real length (3 000 Euler steps, self-imputation amplifies rounding):
+    # SURVEY.md section 8c sets rtol 1e-3 there
+    rtol = RTOL_LONG if name == 'g5_full' else RTOL
+    rows = g['path_rows'] if 'path_rows' in g else slice(None)     # long paths store a subset
+    np.testing.assert_allclose(path_y.cpu().numpy()[rows], g['path_y'], atol=atol, rtol=rtol)
+    np.testing.assert_allclose(hT.cpu().numpy(), g['hT'], atol=atol, rtol=rtol)
     if 'path_h' in g:
         np.testing.assert_allclose(path_h.cpu().numpy(), g['path_h'], atol=atol, rtol=RTOL)
     assert float(loss) == pytest.approx(float(g['loss']), rel=LOSS_RTOL)
@@ -179,11 +183,14 @@ def test_larger_batch_loss_and_grads_vs_oracle(n_paths):
     np.testing.assert_allclose(hT2.cpu().numpy(), h_o.detach().numpy(), atol=ATOL, rtol=RTOL)
 
 
-def test_masked_gradients_match_reference():
+@pytest.mark.parametrize('name', ['g5_masked', 'g5_full'])
+def test_masked_gradients_match_reference(name):
     """BASELINE config 5 shape (PhysioNet-like, d = 41, masked, self-imputation): the
     lockstep backward (adjoint sweep + parallel weight-gradient kernels) against the
-    reference's autograd gradients; covers the t = 0 jump and an empty time slice."""
-    g = Golden('g5_masked')
+    reference's autograd gradients; covers the t = 0 jump and an empty time slice.
+    g5_full is the configuration at its REAL length: 3 000 Euler steps
+    (physionet_train.py:93,326-353), B = 8."""
+    g = Golden(name)
     m = hip_model(g.cfg, g.state_dict()).train()      # dropout_rate = 0
     _, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
     loss.backward()

@@ -1,5 +1,8 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs per kernel (mean per launch).
-Usage: python tools/summarize_pmc.py <dir-with-*_counter_collection.csv> [...] > summary.json
+Usage: python tools/summarize_pmc.py [--paths-per-gpu N --dropout P --command "..."]
+           <dir-with-*_counter_collection.csv> [...] > summary.json
+The workload flags are recorded under "_workload": bench.py reports `roofline.traffic` from
+the summary only when it is benchmarking that same workload.
 FETCH_SIZE / WRITE_SIZE are reported in KiB as rocprofv3 emits them (MI355X_MICROARCH.md
 section HBM: on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x;
 narrow accesses are uncalibrated)."""
@@ -15,8 +18,16 @@ def short(name):
     return name.split('<')[0].split('(')[0]
 
 
+argv = sys.argv[1:]
+workload = {}
+while argv and argv[0].startswith('--'):
+    key, val = argv[0][2:].replace('-', '_'), argv[1]
+    workload[key] = int(val) if key == 'paths_per_gpu' else (float(val) if key == 'dropout' else val)
+    argv = argv[2:]
 out = collections.defaultdict(dict)
-for d in sys.argv[1:]:
+if workload:
+    out['_workload'] = workload
+for d in argv:
     for path in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
