@@ -74,6 +74,11 @@ typedef struct NjodeDims {
 #define NJODE_C_LOSS_IN_BWD 0x10 /* fused step: the loss may be produced by the backward call
                                    (njode_backward_loss_f32, same `loss` pointer) instead of
                                    the forward call -- saves one pass over the observation rows */
+#define NJODE_C_SCHED_KNOWN 0x20 /* the caller states whether the schedule has a tail (Euler steps
+                                   after the last jump) in NJODE_C_SCHED_TAIL; the library then
+                                   never reads the host schedule arrays to choose the plan, so
+                                   njode_backward*_f32 may be called after they were reused     */
+#define NJODE_C_SCHED_TAIL 0x40  /* (with SCHED_KNOWN) k_jump[n_times-1] < n_steps             */
 
 /*
  * Time grid of one forward pass: the float64 clock of NJODE.forward
@@ -99,7 +104,13 @@ typedef struct NjodeBatch {
   const float* start_X;    /* [B, d]                                                  */
   const float* X;          /* [n_obs, d]  sorted by time, then path                   */
   const float* M;          /* [n_obs, d]  0/1 mask, or NULL (required iff MASKED)     */
-  const int32_t* obs_idx;  /* [n_obs]     path index of each row                      */
+  const int32_t* obs_idx;  /* [n_obs]     path index of each row, in [0, B); within one time   */
+                           /*             slice a path has AT MOST ONE row (both collates of    */
+                           /*             the reference guarantee it).  Not checked unless the  */
+                           /*             environment has NJODE_VALIDATE=1 (then: one extra      */
+                           /*             kernel + a sync per forward, NJODE_E_BADARG on a bad  */
+                           /*             index, a duplicate, or n_obs_ot == 0 for an observed  */
+                           /*             path)                                                */
   const int32_t* n_obs_ot; /* [B] observations per path, or NULL if !GET_LOSS         */
   float loss_batch_size;   /* the `batch_size` in compute_loss (models.py:106); for a */
                            /* data-parallel shard pass the GLOBAL batch size          */
@@ -138,8 +149,10 @@ int njode_workspace_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_o
  * Two execution plans, chosen by the library:
  *   - segment plan (unmasked, no RETURN_PATH, schedule ends at the last
  *     observation): every (path, inter-observation segment) is an independent
- *     work item; items are sorted by length and run one per lane.
- *   - lockstep plan (everything else): one lane per path over the shared grid,
+ *     work item; items are sorted by length, 16 of (almost) equal length form a
+ *     tile, a tile runs on one wave (or, the longest ones, on the four waves of a
+ *     block) of the matrix-core kernels.
+ *   - lockstep plan (everything else): 16 paths per wave over the shared grid,
  *     jumps applied under a wave ballot.
  * `weight` is NJODE.weight (models.py:316), `dropout_p` the dropout rate,
  * `seed` the dropout stream seed (only read when TRAIN and dropout_p > 0).

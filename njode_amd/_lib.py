@@ -17,6 +17,7 @@ E_UNSUPPORTED, E_BADARG, E_WORKSPACE, E_HIP = 1, 2, 3, 4
 ACT_TANH, ACT_RELU = 0, 1
 F_MASKED, F_INPUT_CURRENT_T, F_RESIDUAL, F_LOSS_EASY, F_USE_RNN = 0x1, 0x2, 0x4, 0x8, 0x10
 C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD, C_LOSS_IN_BWD = 0x1, 0x2, 0x4, 0x8, 0x10
+C_SCHED_KNOWN, C_SCHED_TAIL = 0x20, 0x40
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
            'njode_forward_f32', 'njode_backward_f32', 'njode_backward_loss_f32',
@@ -25,7 +26,9 @@ EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
            'njode_profile_read',
            # include/njode_producer.h
            'njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
-           'njode_collate_count', 'njode_collate_fill')
+           'njode_collate_count', 'njode_collate_fill',
+           # include/njode_selftest.h
+           'njode_selftest_dropout_words')
 SDE_MODELS = {'BlackScholes': 0, 'OrnsteinUhlenbeck': 1, 'Heston': 2}
 
 
@@ -118,8 +121,12 @@ def lib():
     L.njode_collate_fill.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp,
                                      C.POINTER(C.c_int32), i32, vp, vp, vp, vp]
     for name in ('njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
-                 'njode_collate_count', 'njode_collate_fill'):
+                 'njode_collate_count', 'njode_collate_fill',
+           # include/njode_selftest.h
+           'njode_selftest_dropout_words'):
         getattr(L, name).restype = C.c_int
+    L.njode_selftest_dropout_words.argtypes = [u64, u64, C.c_uint32, C.c_uint32, i32, vp, vp]
+    L.njode_selftest_dropout_words.restype = C.c_int
     _lib = L
     return L
 

@@ -39,7 +39,11 @@ template <class CC> struct FragSize<true, CC> {
   static constexpr int dec = DecS<CC>::type::NALL * 64;
 };
 using FS = FragSize<(HAS_MFMA || HAS_MFMA_LOCK), C>;
-constexpr int MF_FLOATS = FS::ode + FS::enc + FS::dec;
+constexpr int MF_FLOATS = FS::ode + FS::enc + FS::dec + FS::ode;   // + the scaled ODE table (frag2)
+constexpr int FRAG2_OFF = FS::ode + FS::enc + FS::dec;
+template <bool ON, class CC> struct ActSize { static constexpr int value = 0; };
+template <class CC> struct ActSize<true, CC> { static constexpr int value = 8 * MF<CC>::Q1; };
+constexpr int ACT_FLOATS = ActSize<HAS_SPLIT, C>::value;   // stored activations: demo-family shapes
 
 // MFMA launches live in templates on the configuration so that `if constexpr` really
 // discards them for shapes the matrix-core kernels are not written for
@@ -47,7 +51,8 @@ template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st
   if constexpr (HAS_MFMA) {
     using ES = typename EncS<CC>::type;
     using DS = typename DecS<CC>::type;
-    k_pack_frags<CC><<<cdiv(MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag);
+    k_pack_frags12<CC><<<cdiv(2 * MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag, a.frag2,
+                                                                          a.dc.inv_keep);
     k_pack_net<typename CC::Enc, ES><<<cdiv(ES::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_ENC,
                                                                              a.frag_enc);
     k_pack_net<typename CC::Dec, DS><<<cdiv(DS::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_DEC,
@@ -137,6 +142,7 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       if constexpr (ODE == ODE_MFMA) launch_mfma_enc<C, DROP>(a, st);
       else k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
     }
+    if (a.plan_ready) (void)hipStreamWaitEvent(st, (hipEvent_t)a.plan_ready, 0);
     {
       ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma" : "k_ode_fwd_items", st);
       launch_ode_fwd<DROP, false, ODE>(a, st);
@@ -183,6 +189,8 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       MF_FLOATS,
       FS::ode,
       FS::ode + FS::enc,
+      FRAG2_OFF,
+      ACT_FLOATS,
       HAS_MFMA_SWEEP ? 1 : 0,
       HAS_SPLIT ? 1 : 0,
       HAS_MFMA ? 1 : 0};

@@ -1,6 +1,10 @@
-// njode_device.h -- device-side building blocks of the gfx950 NJ-ODE kernels.
+// njode_device.h -- device-side building blocks of the gfx950 NJ-ODE kernels: activations,
+// dropout streams, parameter layout, and the one-chain-per-lane VALU forms of the networks.
 //
-// Execution model used by every kernel here (CDNA4, wave = 64 lanes):
+// The DEFAULT kernels of both plans run on the f32 matrix cores (njode_mfma*.h); what is
+// below the helpers in this file is the VALU form they replaced, still used for GRU models,
+// for network shapes outside the matrix-core kernels' range and for NJODE_ODE=valu A/B runs.
+// Execution model of that VALU form (CDNA4, wave = 64 lanes):
 //   * one independent chain (a path, or a (path, inter-observation segment)
 //     work item) per lane; its hidden state and the activations of the layer
 //     being evaluated live in that lane's VGPRs;
@@ -11,9 +15,8 @@
 //   * weight gradients are a reduction over chains (lanes): each wave stages
 //     (delta, activation) rows in LDS, switches to an 8x8 lane grid that owns
 //     register tiles of dW, and accumulates the outer products from LDS.
-//
-// No MFMA: f32 MFMA runs at the f32 vector rate on gfx950 and BASELINE.json's
-// north_star asks for the VALU form.
+// (BASELINE.json's north_star asked for exactly this form; DESIGN.md section 4a has the
+// measurements that made the matrix cores the default.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

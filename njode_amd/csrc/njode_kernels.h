@@ -49,6 +49,9 @@ struct KArgs {
   float* frag_dec;
   float* frag2;     // scaled A-fragments of the ODE network (k_pack_frags2, njode_ode2.h)
   const void* fragx;  // split-bf16 A-fragments of the ODE network (k_pack_frags_x, njode_odex.h)
+  // segment plan: the part of the plan the encoder rows do not need is built on a helper
+  // stream beside them; the ODE kernel waits for this event (null: everything on one stream)
+  void* plan_ready;
   // batch
   int B, n_obs;
   const float* start_X;
@@ -78,6 +81,11 @@ struct KArgs {
   const int* order;
   const int* t_order;  // paths sorted by tail length (descending): hT items
   const long long* base_s;
+  // stored activations of the ODE network (segment plan, matrix cores): block of the tile
+  // [16 t, 16 t + 16) at Euler step s starts at chain record base16_s[s] + 16 t, where
+  // base16_s = prefix sum of the per-step chain counts rounded up to 16
+  const long long* base16_s;
+  float* act;
   // intermediates
   float* h0row;
   float* h0start;

@@ -30,6 +30,7 @@
 // networks.  Dropout masks are those of the one-wave kernels, whatever role a tile runs in.
 #pragma once
 #include "njode_mfma.h"
+#include "njode_ode2.h"
 
 namespace njode {
 
@@ -102,16 +103,26 @@ NJ_DEV void split_keep_bits(const KArgs& a, int b, int k, int g, int w, uint32_t
 }
 
 // activation of the own tile: al[r] = act(acc[r]) (+ dropout); the bias unit (unit W) is 1
+// (au: the form the forward stores for the backward -- no 1 / (1 - p), a dropped unit as -0.0f)
 template <class C, bool DROP>
-NJ_DEV void split_hidden(const f32x4& acc, float (&al)[4], uint32_t keep, float inv_keep, int g, int w) {
+NJ_DEV void split_hidden(const f32x4& acc, float (&al)[4], float (&au)[4], uint32_t keep, float inv_keep,
+                         int g, int w) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float v = act_f<C::ACT>(acc[r]);
-    if constexpr (DROP) v = ((keep >> r) & 1) ? v * inv_keep : 0.0f;
+    float v = act_f<C::ACT>(acc[r]), u = v;
+    if constexpr (DROP) {
+      const bool k = (keep >> r) & 1;
+      u = k ? v : -0.0f;
+      v = k ? v * inv_keep : 0.0f;
+    }
     al[r] = v;
+    au[r] = u;
   }
   constexpr int QB = C::W / 4, GB = C::W % 4;
-  if (w == QB / 4) al[QB % 4] = g == GB ? 1.0f : al[QB % 4];
+  if (w == QB / 4) {
+    al[QB % 4] = g == GB ? 1.0f : al[QB % 4];
+    au[QB % 4] = g == GB ? 1.0f : au[QB % 4];
+  }
 }
 template <class C, bool DROP>
 NJ_DEV void split_delta(const f32x4& acc, const float (&al)[4], float (&dl)[4], uint32_t keep,
@@ -136,17 +147,48 @@ template <int NQ> NJ_DEV void split_get(lfp X, float (&v)[NQ], int g, int c) {
   for (int q = 0; q < NQ; ++q) v[q] = X[(4 * q + g) * IMG_STRIDE + c];
 }
 
+// wave w's share of a tile's stored-activation block (njode_ode2.h): registers 4w .. 4w+3
+// (no branch around the stores -- registers beyond Q1 go to `trash` -- so that the compiler
+// can count them, see ode2_fwd_single)
+template <class C>
+NJ_DEV void split_act_store(float* act, long long b16, int tile, int lane, int w, const float (&a1u)[4],
+                            const float (&a2u)[4], float* trash) {
+  constexpr int Q1 = MF<C>::Q1;
+  float* p = act_block<C>(act, b16, tile) + lane;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = 4 * w + r < Q1;
+    float* d1 = ok ? p + (4 * w + r) * 64 : trash;
+    float* d2 = ok ? p + (Q1 + 4 * w + r) * 64 : trash;
+    *d1 = a1u[r];
+    *d2 = a2u[r];
+  }
+}
+template <class C>
+NJ_DEV void split_act_load(const float* act, long long b16, int tile, int lane, int w, float (&a1u)[4],
+                           float (&a2u)[4]) {
+  constexpr int Q1 = MF<C>::Q1;
+  const float* p = act_block<C>((float*)act, b16, tile) + lane;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = 4 * w + r < Q1 ? 4 * w + r : 0;
+    const float x1 = p[q * 64], x2 = p[(Q1 + q) * 64];
+    a1u[r] = 4 * w + r < Q1 ? x1 : 0.0f;
+    a2u[r] = 4 * w + r < Q1 ? x2 : 0.0f;
+  }
+}
+
 // forward of the two hidden layers for the own tile; leaves a1 (all units) gathered
 template <class C, bool DROP, bool BWD>
 NJ_DEV void split_hidden_layers(const SplitFrags<C, BWD>& F, lfp X1, const float (&b0)[MF<C>::Q0],
-                                float (&a1l)[4], float (&a2l)[4], uint32_t k1, uint32_t k2,
-                                float inv_keep, int g, int c, int w) {
+                                float (&a1l)[4], float (&a2l)[4], float (&a1u)[4], float (&a2u)[4],
+                                uint32_t k1, uint32_t k2, float inv_keep, int g, int c, int w) {
   using M = MF<C>;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc = z;
 #pragma unroll
   for (int q = 0; q < M::Q0; ++q) acc = mfma4(F.A1[q], b0[q], acc);
-  split_hidden<C, DROP>(acc, a1l, k1, inv_keep, g, w);
+  split_hidden<C, DROP>(acc, a1l, a1u, k1, inv_keep, g, w);
   split_put(X1, a1l, g, c, w);
   block_lds_barrier();                               // (a) a1 of all four tiles is in X1
   float a1[M::Q1];
@@ -159,7 +201,7 @@ NJ_DEV void split_hidden_layers(const SplitFrags<C, BWD>& F, lfp X1, const float
     if (q + 1 < M::Q1) acc1 = mfma4(F.A2[q + 1], a1[q + 1], acc1);
   }
   acc = acc0 + acc1;
-  split_hidden<C, DROP>(acc, a2l, k2, inv_keep, g, w);
+  split_hidden<C, DROP>(acc, a2l, a2u, k2, inv_keep, g, w);
 }
 
 // partial product over the own k-steps, summed over the four waves in fixed order
@@ -180,8 +222,9 @@ NJ_DEV void split_reduce(lfp PR, const f32x4& part, float (&out)[NQ], int lane, 
 
 template <class C> struct OdeFwdSplitLds { static constexpr int FLOATS = XFLOATS + 4 * MF<C>::QH * 64; };
 // B (split): Euler evolve; block `worker` of `n_workers` walks the tiles [tile0, tile1)
-template <class C, bool DROP, bool TAIL>
+template <class C, bool DROP, bool TAIL, bool SAVE>
 NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers, int tile0, int tile1) {
+  static_assert(!(TAIL && SAVE), "tail items are never checkpointed");
   using M = MF<C>;
   lfp X1 = lds_raw, PR = X1 + XFLOATS;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -191,7 +234,7 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
   F.load(a.frag, w, lane);
   __syncthreads();
 
-  const bool SAVE = !TAIL && a.save_traj != 0;
+  constexpr bool ACTS = SAVE;   // compile time: see ode2_fwd_single
   const int n_items = TAIL ? a.B : a.n_obs;
   const int n_tiles = tile1 - tile0;
   float* const trash = a.trash + lane * C::H;
@@ -212,27 +255,29 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
     }
     const int nmax = wave_max(it.n);
     float dt_n = 0.0f, t_n = 0.0f;
-    long long base_n = 0;
+    long long base_n = 0, b16_n = 0;
     if (nmax > 0) {
       const int k0 = it.n > 0 ? it.kbeg : 0;
       dt_n = it.n > 0 ? a.step_dt[k0] : 0.0f;
       t_n = a.step_t[k0];
       base_n = SAVE ? a.base_s[0] : 0;
+      b16_n = ACTS ? a.base16_s[0] : 0;
     }
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
       const float dt = dt_n, t = t_n;
-      const long long base = base_n;
+      const long long base = base_n, b16 = b16_n;
       if (s + 1 < nmax) {
         const bool act_n = s + 1 < it.n;
         const int kn = act_n ? it.kbeg + s + 1 : 0;
         dt_n = act_n ? a.step_dt[kn] : 0.0f;
         t_n = a.step_t[kn];
-        if (SAVE) base_n = a.base_s[s + 1];
+        if constexpr (SAVE) base_n = a.base_s[s + 1];
+        if constexpr (ACTS) b16_n = a.base16_s[s + 1];
       }
-      if (SAVE && w == 0) {
-        float* rec = active ? a.traj + (size_t)(base + j) * C::H : trash;
+      if constexpr (SAVE) {
+        float* rec = (active && w == 0) ? a.traj + (size_t)(base + j) * C::H : trash;
 #pragma unroll
         for (int q = 0; q < M::QH; ++q) {
           const int u = 4 * q + g;
@@ -240,11 +285,12 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
           *dst = h[q];
         }
       }
-      float b0[M::Q0], a1l[4], a2l[4];
+      float b0[M::Q0], a1l[4], a2l[4], a1u[4], a2u[4];
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
       uint32_t k1, k2;
       split_keep_bits<C, DROP>(a, it.b, k, g, w, k1, k2);
-      split_hidden_layers<C, DROP, false>(F, X1, b0, a1l, a2l, k1, k2, a.dc.inv_keep, g, c, w);
+      split_hidden_layers<C, DROP, false>(F, X1, b0, a1l, a2l, a1u, a2u, k1, k2, a.dc.inv_keep, g, c, w);
+      if constexpr (ACTS) split_act_store<C>(a.act, b16, tile, lane, w, a1u, a2u, trash);
       f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -340,7 +386,8 @@ NJ_DEV void ode_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
       uint32_t k1, k2;
       split_keep_bits<C, DROP>(a, it.b, k, g, w, k1, k2);
-      split_hidden_layers<C, DROP, true>(F, X1, b0, a1l, a2l, k1, k2, a.dc.inv_keep, g, c, w);  // (a)
+      float a1u_[4], a2u_[4];
+      split_hidden_layers<C, DROP, true>(F, X1, b0, a1l, a2l, a1u_, a2u_, k1, k2, a.dc.inv_keep, g, c, w);  // (a)
 
       // ---- layer 3: delta3 = dt * lam; dW3 column tile w; W3^T delta3 for the own units
       float d3[M::QH];
@@ -428,13 +475,206 @@ NJ_DEV void ode_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
 }
 
 
+// delta of the own units from the stored activation (unscaled, dropped = -0.0f)
+template <class C, bool DROP>
+NJ_DEV void split_delta_stored(const f32x4& acc, const float (&au)[4], float (&dl)[4], float ik, int g, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float d = acc[r] * ik * dact_stored<C::ACT, DROP>(au[r]);
+    dl[r] = (16 * w + 4 * r + g) < C::W ? d : 0.0f;   // bias / padding units carry no delta
+  }
+}
+// this wave's transposed-product fragments only (the backward on stored activations)
+template <class C> struct SplitFragsT {
+  using M = MF<C>;
+  float B3[M::QH], B2[M::QW], B1[4];
+  NJ_DEV void load(const float* frag, int w, int lane) {
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) B3[q] = frag[(M::B3 + w * M::QH + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < M::QW; ++q) B2[q] = frag[(M::B2 + w * M::QW + q) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 4 * w + r;
+      B1[r] = q < M::QW ? frag[(M::B1 + (q < M::QW ? q : 0)) * 64 + lane] : 0.0f;
+    }
+  }
+};
+
+// C (split, stored activations): as ode_bwd_split, the hidden activations loaded
+template <class C, bool DROP>
+NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers, int tile0, int tile1,
+                          int slab_row) {
+  using M = MF<C>;
+  using NL = typename C::Ode;
+  constexpr int NT1 = 4;
+  static_assert((M::W + 1 + 15) / 16 == NT1 && (M::IN0 + 1 + 15) / 16 == 1,
+                "split kernels: 4 column tiles of [a, 1], one of [in0, 1]");
+  lfp X1 = lds_raw, X2 = X1 + XFLOATS, PR = X2 + XFLOATS;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  lfp imgD3 = PR + 4 * M::QH * 64 + w * 4 * TFLOATS, imgA2 = imgD3 + TFLOATS, imgD1 = imgA2 + TFLOATS,
+      imgB0 = imgD1 + TFLOATS;
+  for (int i = threadIdx.x; i < 2 * XFLOATS + 4 * M::QH * 64 + 4 * 4 * TFLOATS; i += 256) lds_raw[i] = 0.0f;
+  SplitFragsT<C> F;
+  F.load(a.frag, w, lane);
+  __syncthreads();
+
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  f32x4 G3[1][1] = {{z}}, G2[1][NT1] = {{z, z, z, z}}, G1[1][1] = {{z}};
+  float* const trash = a.trash + lane * C::H;
+  const int n_tiles = tile1 - tile0;
+  for (int round = 0; round * n_workers < n_tiles; ++round) {
+    const int rel = snake_tile(round, worker, n_workers);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
+    const int j = tile * 16 + c;
+    const bool valid = j < a.n_obs;
+    Item<C> it;
+    it.template load<false>(a, j, valid);
+    float lam[M::QH];
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
+      lam[q] = (valid && u < C::H) ? v : 0.0f;
+    }
+    const int nmax = wave_max(it.n);
+    auto fetch = [&](int s, float (&hh)[M::QH], float (&x1)[4], float (&x2)[4], float& dtt, float& tt) {
+      const bool act = s < it.n;
+      const int kk = act ? it.kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j) * C::H : 0);
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        const float v = rec[u < C::H ? u : 0];
+        hh[q] = u < C::H ? v : 0.0f;
+      }
+      split_act_load<C>(a.act, a.base16_s[s], tile, lane, w, x1, x2);
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[M::QH], a1_n[4] = {0.f, 0.f, 0.f, 0.f}, a2_n[4] = {0.f, 0.f, 0.f, 0.f}, dt_n = 0.0f, t_n = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
+    if (nmax > 0) fetch(nmax - 1, h_n, a1_n, a2_n, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      float h[M::QH], a1u[4], a2u[4];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) h[q] = h_n[q];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a1u[r] = a1_n[r]; a2u[r] = a2_n[r]; }
+      const float dt = dt_n, t = t_n;
+      if (s > 0) fetch(s - 1, h_n, a1_n, a2_n, dt_n, t_n);
+      float b0[M::Q0], a1l[4], a2l[4];
+      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      // the forward's activations are loaded, not recomputed: with the factor 1 / (1 - p) they
+      // are the images' operands; all-gather a1 for the dW2 product
+      const float ik = DROP ? a.dc.inv_keep : 1.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a1l[r] = a1u[r] * ik; a2l[r] = a2u[r] * ik; }
+      constexpr int QBb = C::W / 4, GBb = C::W % 4;
+      if (w == QBb / 4) {    // the bias unit is 1 (not 1 / (1 - p))
+        a1l[QBb % 4] = g == GBb ? 1.0f : a1l[QBb % 4];
+        a2l[QBb % 4] = g == GBb ? 1.0f : a2l[QBb % 4];
+      }
+      split_put(X1, a1l, g, c, w);
+      block_lds_barrier();                               // (a) a1 of all four tiles is in X1
+
+      // ---- layer 3: delta3 = dt * lam; dW3 column tile w; W3^T delta3 for the own units
+      float d3[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
+      img_write<M::QH>(imgD3, d3, g, c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) imgA2[(4 * r + g) * IMG_STRIDE + c] = a2l[r];
+      img_write<M::Q0>(imgB0, b0, g, c);
+      f32x4 acc = z;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) acc = mfma4(F.B3[q], d3[q], acc);
+      float d2l[4], d1l[4];
+      split_delta_stored<C, DROP>(acc, a2u, d2l, ik, g, w);
+      split_put(X2, d2l, g, c, w);
+      wave_lds_sync();
+      dw_accumulate<1, 1>(imgD3, imgA2, G3, g, c);
+      block_lds_barrier();                             // (b) d2 of all four tiles is in X2
+
+      // ---- layer 2: W2^T delta2 for the own units; dW2 row tile w
+      float d2[M::QW];
+      split_get<M::QW>(X2, d2, g, c);
+      f32x4 acc0 = z, acc1 = z;
+#pragma unroll
+      for (int q = 0; q < M::QW; q += 2) {
+        acc0 = mfma4(F.B2[q], d2[q], acc0);
+        if (q + 1 < M::QW) acc1 = mfma4(F.B2[q + 1], d2[q + 1], acc1);
+      }
+      dw_accumulate<1, NT1>(X2 + 16 * w * IMG_STRIDE, X1, G2, g, c);
+      acc = acc0 + acc1;
+      split_delta_stored<C, DROP>(acc, a1u, d1l, ik, g, w);
+
+      // ---- layer 1: dW1 row tile w; W1^T delta1 split over the own k-steps
+#pragma unroll
+      for (int r = 0; r < 4; ++r) imgD1[(4 * r + g) * IMG_STRIDE + c] = d1l[r];
+      f32x4 part = z;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * w + r < M::QW) part = mfma4(F.B1[r], d1l[r], part);
+      wave_lds_sync();
+      dw_accumulate<1, 1>(imgD1, imgB0, G1, g, c);
+      float gh[M::QH];
+      split_reduce<M::QH>(PR, part, gh, lane, w);      // (c)
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const float th = b0[q];  // = tanh(h) wherever unit 4q + g < H
+        const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
+        lam[q] = fmaf(gh[q], dth, lam[q]);
+      }
+    }
+    if (w == 0) {
+      float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        float* dst = u < C::H ? out + u : trash;
+        *dst = lam[q];
+      }
+    }
+  }
+
+  // ---- flush the tiles this wave owns into the block's slab row (parameter layout)
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int uo = 16 * w + 4 * g + r;
+    if (uo < M::W) {
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) {
+        const int ui = 16 * nt + c;
+        if (ui < M::W) W2[uo * M::W + ui] = G2[0][nt][r];
+        else if (ui == M::W) b2[uo] = G2[0][nt][r];
+      }
+      if (c < M::IN0) W1[uo * M::IN0 + M::col0(c)] = G1[0][0][r];
+      else if (c == M::IN0) b1[uo] = G1[0][0][r];
+    }
+    const int uh = 4 * g + r, ui = 16 * w + c;
+    if (uh < C::H) {
+      if (ui < M::W) W3[uh * M::W + ui] = G3[0][0][r];
+      else if (ui == M::W) b3[uh] = G3[0][0][r];
+    }
+  }
+}
+
+
 // ---- kernels ------------------------------------------------------------------------------
 // Pure split form (tails; plans too small to mix)
 template <class C, bool DROP, bool TAIL>
 __global__ void __launch_bounds__(256, 2) k_ode_fwd_split(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS];
   const int n_items = TAIL ? a.B : a.n_obs;
-  ode_fwd_split<C, DROP, TAIL>(a, (lfp)lds_raw, blockIdx.x, gridDim.x, 0, (n_items + 15) / 16);
+  // (only launched for the tails: the items of a saving forward go through the mixed kernel)
+  ode_fwd_split<C, DROP, TAIL, false>(a, (lfp)lds_raw, blockIdx.x, gridDim.x, 0, (n_items + 15) / 16);
 }
 
 // Mixed form.  Tiles are sorted by length; the split point T (k_split_point, on the device)
@@ -448,15 +688,21 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS];
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_fwd;
   const int T = (int)a.base_s[a.K + 2];
+  const bool save = a.save_traj != 0;   // wave-uniform: a training forward stores checkpoints
+                                         // and activations, an evaluation forward nothing
   if ((int)blockIdx.x < ns) {
-    ode_fwd_split<C, DROP, false>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
+    if (save) ode_fwd_split<C, DROP, false, true>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
+    else ode_fwd_split<C, DROP, false, false>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
   } else {
     const int wave = ((int)blockIdx.x - ns) * 4 + (threadIdx.x >> 6);
-    ode_fwd_single<C, DROP, false>(a, threadIdx.x & 63, wave, ((int)gridDim.x - ns) * 4, T, n_tiles);
+    // one-wave role on the scaled fragments (njode_ode2.h): same masks, same values to rounding
+    const int nw = ((int)gridDim.x - ns) * 4;
+    if (save) ode2_fwd_single<C, DROP, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
+    else ode2_fwd_single<C, DROP, false, false>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
   }
 }
 template <class C> struct OdeBwdMixedLds {
-  static constexpr int A = OdeBwdSingleLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;
+  static constexpr int A = OdeBwdActLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;
   static constexpr int FLOATS = A > B ? A : B;
 };
 // one slab row per block
@@ -465,11 +711,13 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdMixedLds<C>::FLOATS];
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_blocks;
   const int T = (int)a.base_s[a.K + 1];
+  // both roles read the forward's stored activations (njode_ode2.h): the mixed kernels only
+  // run with a saved forward, which always has them
   if ((int)blockIdx.x < ns) {
-    ode_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
+    ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
   } else {
     const int wave = ((int)blockIdx.x - ns) * 4 + (threadIdx.x >> 6);
-    ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
+    ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
   }
 }
 

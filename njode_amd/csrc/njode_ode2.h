@@ -35,17 +35,13 @@ template <class C> struct Ode2Scale {
 //   F1 = S [W1 | b1]      F2 = S [ik W2 | b2]     F3 = [ik W3 | b3]
 //   B3 = ik W3^T          B2 = ik W2^T            B1 = W1^T (h rows)
 // S = 2 log2(e) for tanh networks (1 for relu), ik = 1 / (1 - p) (1 without dropout).
-template <class C>
-__global__ void k_pack_frags2(const float* __restrict__ P, float* __restrict__ frag, float ik) {
+template <class C> NJ_DEV float ode_frag_value(const float* __restrict__ P, int idx, float S, float ik) {
   using M = MF<C>;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M::NALL * 64) return;
   const int f = idx >> 6, l = idx & 63, g = l >> 4, c = l & 15;
   const float* Po = P + C::OFF_ODE;
   using NL = typename C::Ode;
   const float *W1 = Po + NL::woff(0), *b1 = Po + NL::boff(0), *W2 = Po + NL::woff(1),
               *b2 = Po + NL::boff(1), *W3 = Po + NL::woff(2), *b3 = Po + NL::boff(2);
-  constexpr float S = Ode2Scale<C>::S;
   float v = 0.0f;
   if (f < M::F2) {
     const int mt = (f - M::F1) / M::Q0, q = (f - M::F1) % M::Q0;
@@ -72,7 +68,24 @@ __global__ void k_pack_frags2(const float* __restrict__ P, float* __restrict__ f
     const int u = row_unit(mt, c), uo = 4 * q + g;
     if (u < M::IN0 && uo < M::W) v = W1[uo * M::IN0 + M::col0(u)];
   }
-  frag[idx] = v;
+  return v;
+}
+template <class C>
+__global__ void k_pack_frags2(const float* __restrict__ P, float* __restrict__ frag, float ik) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= MF<C>::NALL * 64) return;
+  frag[idx] = ode_frag_value<C>(P, idx, Ode2Scale<C>::S, ik);
+}
+// both tables of the ODE network in one launch: the plain one (njode_mfma.h: four-wave role,
+// lockstep kernels) and the scaled one
+template <class C>
+__global__ void k_pack_frags12(const float* __restrict__ P, float* __restrict__ frag,
+                               float* __restrict__ frag2, float ik) {
+  constexpr int N = MF<C>::NALL * 64;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * N) return;
+  if (idx < N) frag[idx] = ode_frag_value<C>(P, idx, 1.0f, 1.0f);
+  else frag2[idx - N] = ode_frag_value<C>(P, idx - N, Ode2Scale<C>::S, ik);
 }
 
 // activation of a pre-scaled pre-activation: tanh(z) from z' = 2 log2(e) z
@@ -83,6 +96,45 @@ template <int ACT> NJ_DEV float act2_f(float zs) {
   } else {
     return fmaxf(zs, 0.0f);
   }
+}
+
+
+// ---- stored activations ----------------------------------------------------------------
+// While the f32 pipe (matrix + vector: one pipe on gfx950) bounds the ODE kernels, HBM idles:
+// the forward stores the two hidden activation vectors of every Euler step (WITHOUT the
+// inverted-dropout factor; a dropped unit as -0.0f) and the backward reads them instead of
+// recomputing 68 of its 241 MFMAs, 58 transcendentals and the dropout stream.  Layout: the
+// block of tile t at Euler step s starts at chain record base16_s[s] + 16 t (KArgs), a record
+// is 8 Q1 floats; inside the block register q of layer l of lane `lane` sits at
+// (l Q1 + q) 64 + lane: every wave-level store / load is one contiguous 256-byte line.
+template <class C> NJ_DEV float* act_block(float* act, long long b16, int tile) {
+  return act + (size_t)(b16 + 16 * (long long)tile) * (8 * MF<C>::Q1);
+}
+template <class C>
+NJ_DEV void act_store(float* act, long long b16, int tile, int lane, const float (&a1)[MF<C>::Q1],
+                      const float (&a2)[MF<C>::Q1]) {
+  constexpr int Q1 = MF<C>::Q1;
+  float* p = act_block<C>(act, b16, tile) + lane;
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) p[q * 64] = a1[q];
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) p[(Q1 + q) * 64] = a2[q];
+}
+template <class C>
+NJ_DEV void act_load(const float* act, long long b16, int tile, int lane, float (&a1)[MF<C>::Q1],
+                     float (&a2)[MF<C>::Q1]) {
+  constexpr int Q1 = MF<C>::Q1;
+  const float* p = act_block<C>((float*)act, b16, tile) + lane;
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) a1[q] = p[q * 64];
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) a2[q] = p[(Q1 + q) * 64];
+}
+// act'(z) from a stored activation; 0 for a dropped unit (stored as -0.0f)
+template <int ACT, bool DROP> NJ_DEV float dact_stored(float av) {
+  const float d = dact_f<ACT>(av);
+  if constexpr (DROP) return __float_as_uint(av) == 0x80000000u ? 0.0f : d;
+  else return d;
 }
 
 // one xorshift32 word: two 16-bit keep decisions (same stream as njode_mfma.h)
@@ -106,8 +158,10 @@ NJ_DEV void hidden_pair(const f32x4& t0, const f32x4& t1, float (&av)[MF<C>::Q1]
       float v1 = q + 1 < Q1 ? act2_f<C::ACT>(r + 1 < 4 ? t0[(r + 1) & 3] : t1[(r + 1) & 3]) : 0.0f;
       if constexpr (DROP) {
         const uint32_t w = xs32(s);
-        v0 = (w & 0xffffu) >= thr16 ? v0 : 0.0f;
-        v1 = (w >> 16) >= thr16 ? v1 : 0.0f;
+        // a dropped unit is -0.0f: a zero for every product, and the backward (which reads the
+        // stored activations instead of recomputing them) can tell it from a kept unit at 0
+        v0 = (w & 0xffffu) >= thr16 ? v0 : -0.0f;
+        v1 = (w >> 16) >= thr16 ? v1 : -0.0f;
       }
       av[q] = v0;
       if (q + 1 < Q1) av[q + 1] = v1;
@@ -181,14 +235,18 @@ NJ_DEV void out_layer2(const float (&A3)[MF<C>::MTH][MF<C>::Q1], const float (&a
 // B (v2): Euler evolve of every item; worker `wave` of `n_waves` walks the tiles
 // [tile0, tile1) in snake order.  Same contract as ode_fwd_single (njode_mfma.h) with the
 // scaled fragment table a.frag2.
-template <class C, bool DROP, bool TAIL>
+// SAVE (compile time: checkpoints + activations are stored without a branch, so the compiler
+// can COUNT them -- with a runtime `if` around the stores every `s_waitcnt vmcnt` that waits for
+// the next step's prefetched scalars conservatively also drained the stores: +13 % on the kernel)
+template <class C, bool DROP, bool TAIL, bool SAVE>
 NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int tile0, int tile1) {
+  static_assert(!(TAIL && SAVE), "tail items are never checkpointed");
   using M = MF<C>;
   const int g = lane >> 4, c = lane & 15;
   Ode2FwdFrags<C> F;
   F.load(a.frag2, lane);
 
-  const bool SAVE = !TAIL && a.save_traj != 0;
+  constexpr bool ACTS = SAVE;   // the saving forward of these kernels always has a.act
   const int n_items = TAIL ? a.B : a.n_obs;
   const int n_tiles = tile1 - tile0;
   float* const trash = a.trash + lane * C::H;
@@ -209,26 +267,28 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
     }
     const int nmax = wave_max(it.n);
     float dt_n = 0.0f, t_n = 0.0f;
-    long long base_n = 0;
+    long long base_n = 0, b16_n = 0;
     if (nmax > 0) {
       const int k0 = it.n > 0 ? it.kbeg : 0;
       dt_n = it.n > 0 ? a.step_dt[k0] : 0.0f;
       t_n = a.step_t[k0];
       base_n = SAVE ? a.base_s[0] : 0;
+      b16_n = ACTS ? a.base16_s[0] : 0;
     }
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
       const float dt = dt_n, t = t_n;
-      const long long base = base_n;
+      const long long base = base_n, b16 = b16_n;
       if (s + 1 < nmax) {
         const bool act_n = s + 1 < it.n;
         const int kn = act_n ? it.kbeg + s + 1 : 0;
         dt_n = act_n ? a.step_dt[kn] : 0.0f;
         t_n = a.step_t[kn];
-        if (SAVE) base_n = a.base_s[s + 1];
+        if constexpr (SAVE) base_n = a.base_s[s + 1];
+        if constexpr (ACTS) b16_n = a.base16_s[s + 1];
       }
-      if (SAVE) {
+      if constexpr (SAVE) {
         float* rec = active ? a.traj + (size_t)(base + j) * C::H : trash;
 #pragma unroll
         for (int q = 0; q < M::QH; ++q) {
@@ -248,6 +308,7 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
       float a1[M::Q1], a2[M::Q1];
       hidden_layer2<C, DROP, M::Q0>(F.A1, b0, a1, st, a.dc.thr16, g);
       hidden_layer2<C, DROP, M::Q1>(F.A2, a1, a2, st, a.dc.thr16, g);
+      if constexpr (ACTS) act_store<C>(a.act, b16, tile, lane, a1, a2);
       f32x4 f[M::MTH];
       out_layer2<C>(F.A3, a2, f);
 #pragma unroll
@@ -263,6 +324,525 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
   }
 }
 
+
+
+// ---- the one-wave backward of njode_mfma.h on the scaled fragments ---------------------------
+// hidden activation from accumulator tiles of PRE-SCALED pre-activations: a[q] = act (+ dropout
+// select, no scale), bias unit = 1
+template <class C, bool DROP>
+NJ_DEV void hidden_from_acc2(const f32x4 (&acc)[MF<C>::MT1], float (&av)[MF<C>::Q1], uint32_t keep, int g) {
+  constexpr int Q1 = MF<C>::Q1;
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) {
+    float v = act2_f<C::ACT>(acc[q / 4][q % 4]);
+    if constexpr (DROP) v = ((keep >> q) & 1) ? v : 0.0f;
+    av[q] = v;
+  }
+  constexpr int QB = MF<C>::W / 4, GB = MF<C>::W % 4;
+  av[QB] = g == GB ? 1.0f : av[QB];
+}
+// delta of a hidden layer: the transposed product already carries 1 / (1 - p) (fragments B3 / B2)
+template <class C, bool DROP>
+NJ_DEV void hidden_delta2(const f32x4 (&acc)[MF<C>::MT1], const float (&av)[MF<C>::Q1],
+                          float (&dv)[MF<C>::QW], uint32_t keep) {
+#pragma unroll
+  for (int q = 0; q < MF<C>::QW; ++q) {
+    const float d = acc[q / 4][q % 4] * dact_f<C::ACT>(av[q]);
+    if constexpr (DROP) dv[q] = ((keep >> q) & 1) ? d : 0.0f;
+    else dv[q] = d;
+  }
+}
+
+template <class C, bool DROP>
+NJ_DEV void ode2_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
+                           int slab_row) {
+  using M = MF<C>;
+  using NL = typename C::Ode;
+  using FR = OdeLdsFrags<C>;
+  constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
+  constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  lfp img_d = lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
+  lfp fimg = lds_raw + 4 * 2 * IMG_FLOATS;
+  FR::stage(fimg, a.frag2, threadIdx.x, 256);   // scaled fragments (k_pack_frags2)
+  // image rows that no vector writes must be finite (they meet zero deltas / feed
+  // accumulator entries that are never flushed)
+  for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  __syncthreads();
+  FR F;
+  F.init(fimg, lane);
+
+  f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < M::MTH; ++i)
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G3[i][n] = zero4;
+#pragma unroll
+  for (int i = 0; i < M::MT1; ++i) {
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G2[i][n] = zero4;
+#pragma unroll
+    for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
+  }
+  float* const trash = a.trash + threadIdx.x * C::H;
+  const int n_tiles = tile1 - tile0;
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
+    const int j = tile * 16 + c;
+    const bool valid = j < a.n_obs;
+    Item<C> it;
+    it.template load<false>(a, j, valid);
+    float lam[M::QH];
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
+      lam[q] = (valid && u < C::H) ? v : 0.0f;
+    }
+    const int nmax = wave_max(it.n);
+    // state and scalars of a step are loaded while the previous one is processed
+    auto fetch = [&](int s, float (&hh)[M::QH], float& dtt, float& tt) {
+      const bool act = s < it.n;
+      const int kk = act ? it.kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j) * C::H : 0);
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        const float v = rec[u < C::H ? u : 0];
+        hh[q] = u < C::H ? v : 0.0f;
+      }
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[M::QH], dt_n = 0.0f, t_n = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
+    if (nmax > 0) fetch(nmax - 1, h_n, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const bool active = s < it.n;
+      const int k = active ? it.kbeg + s : 0;
+      float h[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) h[q] = h_n[q];
+      const float dt = dt_n, t = t_n;
+      if (s > 0) fetch(s - 1, h_n, dt_n, t_n);
+      float b0[M::Q0];
+      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      uint32_t k1 = 0, k2 = 0;
+      if constexpr (DROP) {
+        const unsigned long long gid = a.gid0 + it.b;
+        uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                                 (uint32_t)k, NET_ODE);
+        k1 = keep_bits<M::Q1>(st, a.dc.thr16);
+        k2 = keep_bits<M::Q1>(st, a.dc.thr16);
+      }
+      // ---- recompute the two hidden layers
+      F.begin();
+      f32x4 acc[M::MT1];
+      float a1[M::Q1], a2[M::Q1];
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::Q0; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.a1(mt, q), b0[q], acc[mt]);
+      hidden_from_acc2<C, DROP>(acc, a1, k1, g);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.a2(mt, q), a1[q], acc[mt]);
+      hidden_from_acc2<C, DROP>(acc, a2, k2, g);
+
+      // ---- layer 3: h' = h + dt f  =>  delta3 = dt * lam (zero for inactive chains)
+      float d3[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
+      img_write<M::QH>(img_d, d3, g, c);
+      img_write<M::Q1>(img_a, a2, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
+      float d2[M::QW];
+      hidden_delta2<C, DROP>(acc, a2, d2, k2);
+      wave_lds_sync();
+
+      // ---- layer 2
+      img_write<M::QW>(img_d, d2, g, c);
+      img_write<M::Q1>(img_a, a1, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
+      float d1[M::QW];
+      hidden_delta2<C, DROP>(acc, a1, d1, k1);
+      wave_lds_sync();
+
+      // ---- layer 1
+      img_write<M::QW>(img_d, d1, g, c);
+      img_write<M::Q0>(img_a, b0, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
+      f32x4 acch[M::MTH];
+#pragma unroll
+      for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MTH; ++mt) acch[mt] = mfma4(F.b1(mt, q), d1[q], acch[mt]);
+      // adjoint of the state: lam += (W1^T delta1)[h rows] * (1 - tanh(h)^2)
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const float th = b0[q];  // = tanh(h) wherever unit 4q + g < H
+        const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
+        lam[q] = fmaf(acch[q / 4][q % 4], dth, lam[q]);
+      }
+      wave_lds_sync();
+    }
+    float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = lam[q];
+    }
+  }
+
+  // ---- flush: the block's four workers share ONE slab row (parameter layout), so the
+  // reduction kernels read one row per block, not per wave.  Waves 1-3 park their register
+  // tiles in LDS (free by now), wave 0 adds them in fixed order (deterministic) and stores.
+  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
+  static_assert(3 * NG * 64 * 4 <= OdeBwdSingleLds<C>::FLOATS, "tile reduction does not fit the LDS");
+  __syncthreads();
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
+  auto for_tiles = [&](auto f) {
+    int i = 0;
+#pragma unroll
+    for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT0; ++nt) f(G1[mt][nt], i++);
+  };
+  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+  __syncthreads();
+  if (wv != 0) return;
+  for_tiles([&](f32x4& t, int i) {
+    t += red[(0 * NG + i) * 64 + lane];
+    t += red[(1 * NG + i) * 64 + lane];
+    t += red[(2 * NG + i) * 64 + lane];
+  });
+  // the activations carry no inverted-dropout factor here: it goes on once, at the flush
+  const float ik = DROP ? a.dc.inv_keep : 1.0f;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < M::W) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W2[uo * M::W + ui] = ik * G2[mt][nt][r];
+          else if (ui == M::W) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::IN0) W1[uo * M::IN0 + M::col0(ui)] = G1[mt][nt][r];
+          else if (ui == M::IN0) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < C::H) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W3[uo * M::W + ui] = ik * G3[mt][nt][r];
+          else if (ui == M::W) b3[uo] = G3[mt][nt][r];
+        }
+      }
+    }
+}
+
+
+// C (stored activations): reverse Euler sweep of every segment + d loss / d ODE params.
+// Same contract and worker layout as ode_bwd_single (njode_mfma.h); per Euler step the two
+// hidden activation vectors are LOADED (prefetched one step ahead with the checkpoint), so
+// only the transposed products (77 MFMAs) and the weight-gradient products (96) remain, the
+// LDS holds only the transposed fragments, and no dropout stream is drawn.
+template <class C> struct OdeLdsFragsT {
+  using M = MF<C>;
+  static constexpr int NVEC = M::NALL - M::NFWD;
+  lfp base, cur;
+  static NJ_DEV void stage(lfp img, const float* frag, int tid, int nthreads) {
+    for (int i = tid; i < NVEC * 64; i += nthreads) img[i] = frag[M::NFWD * 64 + i];
+  }
+  NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; }
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lfp)(unsigned long long)v;
+  }
+  NJ_DEV float b3(int mt, int q) const { return cur[(M::B3 - M::NFWD + mt * M::QH + q) * 64]; }
+  NJ_DEV float b2(int mt, int q) const { return cur[(M::B2 - M::NFWD + mt * M::QW + q) * 64]; }
+  NJ_DEV float b1(int mt, int q) const { return cur[(M::B1 - M::NFWD + mt * M::QW + q) * 64]; }
+};
+template <class C> struct OdeBwdActLds {
+  using M = MF<C>;
+  static constexpr int NG = M::MTH * ((M::W + 1 + 15) / 16) + M::MT1 * ((M::W + 1 + 15) / 16) +
+                            M::MT1 * ((M::IN0 + 1 + 15) / 16);
+  static constexpr int BODY = 4 * 2 * IMG_FLOATS + OdeLdsFragsT<C>::NVEC * 64;
+  static constexpr int RED = 3 * NG * 64 * 4;      // the block's final tile reduction
+  static constexpr int FLOATS = BODY > RED ? BODY : RED;
+};
+template <class C, bool DROP>
+NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
+                            int slab_row) {
+  using M = MF<C>;
+  using NL = typename C::Ode;
+  using FR = OdeLdsFragsT<C>;
+  constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
+  constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  lfp img_d = lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
+  lfp fimg = lds_raw + 4 * 2 * IMG_FLOATS;
+  FR::stage(fimg, a.frag2, threadIdx.x, 256);
+  for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  __syncthreads();
+  FR F;
+  F.init(fimg, lane);
+
+  f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < M::MTH; ++i)
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G3[i][n] = zero4;
+#pragma unroll
+  for (int i = 0; i < M::MT1; ++i) {
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G2[i][n] = zero4;
+#pragma unroll
+    for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
+  }
+  float* const trash = a.trash + threadIdx.x * C::H;
+  const int n_tiles = tile1 - tile0;
+  for (int round = 0; round * n_waves < n_tiles; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_tiles) continue;
+    const int tile = tile0 + rel;
+    const int j = tile * 16 + c;
+    const bool valid = j < a.n_obs;
+    Item<C> it;
+    it.template load<false>(a, j, valid);
+    float lam[M::QH];
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
+      lam[q] = (valid && u < C::H) ? v : 0.0f;
+    }
+    const int nmax = wave_max(it.n);
+    // checkpoint, activations and scalars of a step are loaded while the previous one runs
+    auto fetch = [&](int s, float (&hh)[M::QH], float (&x1)[M::Q1], float (&x2)[M::Q1], float& dtt,
+                     float& tt) {
+      const bool act = s < it.n;
+      const int kk = act ? it.kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j) * C::H : 0);
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        const float v = rec[u < C::H ? u : 0];
+        hh[q] = u < C::H ? v : 0.0f;
+      }
+      act_load<C>(a.act, a.base16_s[s], tile, lane, x1, x2);
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[M::QH], a1_n[M::Q1], a2_n[M::Q1], dt_n = 0.0f, t_n = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::Q1; ++q) { a1_n[q] = 0.0f; a2_n[q] = 0.0f; }
+    if (nmax > 0) fetch(nmax - 1, h_n, a1_n, a2_n, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      float h[M::QH], a1[M::Q1], a2[M::Q1];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) h[q] = h_n[q];
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q) { a1[q] = a1_n[q]; a2[q] = a2_n[q]; }
+      const float dt = dt_n, t = t_n;
+      if (s > 0) fetch(s - 1, h_n, a1_n, a2_n, dt_n, t_n);
+      float b0[M::Q0];
+      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      F.begin();
+
+      // ---- layer 3: h' = h + dt f  =>  delta3 = dt * lam (zero for inactive chains)
+      float d3[M::QH];
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
+      img_write<M::QH>(img_d, d3, g, c);
+      img_write<M::Q1>(img_a, a2, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
+      f32x4 acc[M::MT1];
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
+      float d2[M::QW];
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q) d2[q] = acc[q / 4][q % 4] * dact_stored<C::ACT, DROP>(a2[q]);
+      wave_lds_sync();
+
+      // ---- layer 2
+      img_write<M::QW>(img_d, d2, g, c);
+      img_write<M::Q1>(img_a, a1, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
+      float d1[M::QW];
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q) d1[q] = acc[q / 4][q % 4] * dact_stored<C::ACT, DROP>(a1[q]);
+      wave_lds_sync();
+
+      // ---- layer 1
+      img_write<M::QW>(img_d, d1, g, c);
+      img_write<M::Q0>(img_a, b0, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
+      f32x4 acch[M::MTH];
+#pragma unroll
+      for (int mt = 0; mt < M::MTH; ++mt) {
+        f32x4 e = zero4, o = zero4;
+#pragma unroll
+        for (int q = 0; q < M::QW; q += 2) {
+          e = mfma4(F.b1(mt, q), d1[q], e);
+          if (q + 1 < M::QW) o = mfma4(F.b1(mt, q + 1), d1[q + 1], o);
+        }
+        acch[mt] = e + o;
+      }
+      // adjoint of the state: lam += (W1^T delta1)[h rows] * (1 - tanh(h)^2)
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const float th = b0[q];  // = tanh(h) wherever unit 4q + g < H
+        const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
+        lam[q] = fmaf(acch[q / 4][q % 4], dth, lam[q]);
+      }
+      wave_lds_sync();
+    }
+    float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) {
+      const int u = 4 * q + g;
+      float* dst = u < C::H ? out + u : trash;
+      *dst = lam[q];
+    }
+  }
+
+  // ---- flush (as ode_bwd_single): one slab row per block
+  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
+  static_assert(3 * NG * 64 * 4 <= OdeBwdActLds<C>::FLOATS, "tile reduction does not fit the LDS");
+  __syncthreads();
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
+  auto for_tiles = [&](auto f) {
+    int i = 0;
+#pragma unroll
+    for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT0; ++nt) f(G1[mt][nt], i++);
+  };
+  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+  __syncthreads();
+  if (wv != 0) return;
+  for_tiles([&](f32x4& t, int i) {
+    t += red[(0 * NG + i) * 64 + lane];
+    t += red[(1 * NG + i) * 64 + lane];
+    t += red[(2 * NG + i) * 64 + lane];
+  });
+  // the stored activations carry no inverted-dropout factor: it goes on once, here
+  const float ik = DROP ? a.dc.inv_keep : 1.0f;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < M::W) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W2[uo * M::W + ui] = ik * G2[mt][nt][r];
+          else if (ui == M::W) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::IN0) W1[uo * M::IN0 + M::col0(ui)] = G1[mt][nt][r];
+          else if (ui == M::IN0) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < C::H) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W3[uo * M::W + ui] = ik * G3[mt][nt][r];
+          else if (ui == M::W) b3[uo] = G3[mt][nt][r];
+        }
+      }
+    }
+}
 
 // ---- backward: producer / consumer ------------------------------------------------------
 // One image set = the six [unit][chain] images of one Euler step of one tile, rows packed

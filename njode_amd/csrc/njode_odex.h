@@ -940,6 +940,13 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
   }
   float* const trash = a.trash + threadIdx.x * C::H;
   const int n_tiles = tile1 - tile0;
+#ifdef NJ_XSTAMP
+  unsigned long long ts_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_prev = 0;
+  unsigned ts_steps = 0;
+#define XSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)"); ts_acc[i] += now_ - ts_prev; ts_prev = now_; }
+#else
+#define XSTAMP(i)
+#endif
   for (int round = 0; round * n_waves < n_tiles; ++round) {
     const int rel = snake_tile(round, wave, n_waves);
     if (rel >= n_tiles) continue;
@@ -974,6 +981,11 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
     float h_n[4] = {0.f, 0.f, 0.f, 0.f}, dt_n = 0.0f, t_n = 0.0f;
     if (nmax > 0) fetch(nmax - 1, h_n, dt_n, t_n);
     for (int s = nmax - 1; s >= 0; --s) {
+#ifdef NJ_XSTAMP
+      ts_prev = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)");
+      ++ts_steps;
+#endif
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
       float h[4];
@@ -1012,9 +1024,11 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
       XOp B1[X::KS1];
 #pragma unroll
       for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(F.a1(mt), B0, z);
+      XSTAMP(0)   // in0 + delta3 + layer-1 MFMAs
       x_hidden<C, DROP, true>(acc, av, da1, st, a.dc.thr16, g);
 #pragma unroll
       for (int ks = 0; ks < X::KS1; ++ks) pack8(av[ks], B1[ks]);
+      XSTAMP(1)   // activation + split of a1
 #pragma unroll
       for (int mt = 0; mt < X::MT1; ++mt) {
         f32x4 tt = z;
@@ -1022,6 +1036,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
         for (int ks = 0; ks < X::KS1; ++ks) tt = xmma(F.a2(mt, ks), B1[ks], tt);
         acc[mt] = tt;
       }
+      XSTAMP(2)   // layer-2 MFMAs
       x_hidden<C, DROP, true>(acc, av, da2, st, a.dc.thr16, g);
       {
         XOp B2;
@@ -1032,6 +1047,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
         }
       }
       wave_lds_sync();
+      XSTAMP(3)   // activation + split + image of a2
       // ---- dW3 = delta3 (x) [a2, 1]
       XOp Ba[X::MT1];
       {
@@ -1043,6 +1059,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
           G3[nt] = xmma_oo(Ad, Ba[nt], G3[nt]);
         }
       }
+      XSTAMP(4)   // dW3 reads + MFMAs
       // delta2 = (ik W3^T delta3) * act'(z2) * mask2
 #pragma unroll
       for (int mt = 0; mt < X::MT1; ++mt) acc[mt] = xmma(F.b3(mt), Bd3, z);
@@ -1055,6 +1072,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
 #pragma unroll
       for (int ks = 0; ks < X::KS1; ++ks) pack8(dv[ks], Bd[ks]);
       wave_lds_sync();
+      XSTAMP(5)   // W3^T delta3 + delta2 + split
       // ---- dW2 = delta2 (x) [a1, 1]: a1 image -> registers, then the delta2 image in its place
 #pragma unroll
       for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(wide, I::WIDE_RS, I::WIDE_PIECE, B1[ks], ks, g, c);
@@ -1072,6 +1090,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
 #pragma unroll
         for (int nt = 0; nt < X::MT1; ++nt) G2[mt][nt] = xmma_oo(Ad, Ba[nt], G2[mt][nt]);
       }
+      XSTAMP(6)   // dW2: images, reads, MFMAs
       // delta1 = (ik W2^T delta2) * act'(z1) * mask1
 #pragma unroll
       for (int mt = 0; mt < X::MT1; ++mt) {
@@ -1087,6 +1106,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
 #pragma unroll
       for (int ks = 0; ks < X::KS1; ++ks) pack8(dv[ks], Bd[ks]);
       wave_lds_sync();
+      XSTAMP(7)   // W2^T delta2 + delta1 + split
       // ---- dW1 = delta1 (x) [in0, 1]
 #pragma unroll
       for (int ks = 0; ks < X::KS1; ++ks) ximg_put_wide(wide, I::WIDE_RS, I::WIDE_PIECE, Bd[ks], ks, g, c);
@@ -1105,6 +1125,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
           for (int nt = 0; nt < X::NT0; ++nt) G1[mt][nt] = xmma_oo(Ad, Bi[nt], G1[mt][nt]);
         }
       }
+      XSTAMP(8)   // dW1
       // adjoint of the state: lam += (W1^T delta1)[state rows] * (1 - tanh(h)^2)
       f32x4 f = z;
 #pragma unroll
@@ -1115,6 +1136,7 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
         lam[r] = fmaf(f[r], dth, lam[r]);
       }
       wave_lds_sync();
+      XSTAMP(9)   // W1^T delta1 + lam
     }
     float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
 #pragma unroll
@@ -1125,6 +1147,13 @@ NJ_DEV void odex_bwd_wg(const KArgs& a, char __attribute__((address_space(3)))* 
     }
   }
 
+#ifdef NJ_XSTAMP
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long* o = (unsigned long long*)a.g_h0;
+    for (int i = 0; i < 10; ++i) o[i] = ts_acc[i];
+    o[10] = ts_steps;
+  }
+#endif
   // ---- flush: the block's workers sum their tiles through LDS (fixed order, two rounds for
   // NW = 8) into ONE slab row
   constexpr int NG = I::NG;

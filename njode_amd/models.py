@@ -462,7 +462,10 @@ class NJODE(torch.nn.Module):
                              int(self.dp_path_offset))
         flags = ((_lib.C_TRAIN if self.training else 0) | (_lib.C_GET_LOSS if get_loss else 0)
                  | (_lib.C_RETURN_PATH if return_path else 0)
-                 | (_lib.C_SAVE_BWD if save_bwd else 0))
+                 | (_lib.C_SAVE_BWD if save_bwd else 0)
+                 # the plan decision travels with the call: the backward never re-reads the
+                 # pinned schedule buffer, which the ring may have handed to a later forward
+                 | _lib.C_SCHED_KNOWN | (_lib.C_SCHED_TAIL if sched.has_tail() else 0))
         need = ctypes.c_size_t(0)
         _lib.check(L.njode_workspace_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
                                            ctypes.byref(need)))
@@ -497,6 +500,11 @@ class NJODE(torch.nn.Module):
         (``NJODE_C_LOSS_IN_BWD``, see ``loss_and_grad``)."""
         L = _lib.lib()
         stream = torch.cuda.current_stream()
+        if call.ws_slot is None:
+            raise RuntimeError(
+                'the workspace saved by this forward was already released: a second backward '
+                'through the same NJODE forward (retain_graph) is not supported -- run the '
+                'forward again')
         if loss is not None:
             _lib.check(L.njode_backward_loss_f32(
                 ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),

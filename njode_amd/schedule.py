@@ -60,6 +60,12 @@ class Schedule:
     def n_rows(self):
         return 1 + self.n_steps + self.n_times
 
+    def has_tail(self):
+        """Euler steps after the last jump (until_T) -- or no jump at all."""
+        if self.n_times == 0:
+            return self.n_steps > 0
+        return int(self.k_jump[-1]) < self.n_steps
+
     def packed_nbytes(self):
         return 4 * (2 * self.n_steps + 3 * self.n_times + 1)
 

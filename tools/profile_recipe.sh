@@ -16,12 +16,12 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="$ROOT/bench.py --no-cpu-baseline --no-small-batch"
 REGEX='k_ode|k_jump|k_encode|k_reduce|k_adam|k_pack|k_row_time|k_dense|k_traj|k_sum'
 
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $BENCH --steps 20 \
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $BENCH --steps 20 \
   > $OUT/stats_bench.json 2> $OUT/stats.err
 
 pmc() {   # name, counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --kernel-include-regex "$REGEX" -d $OUT/pmc_$name -o pmc -- \
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv --kernel-include-regex "$REGEX" -d $OUT/pmc_$name -o pmc -- \
     python3 $BENCH --steps 3 --warmup 1 --no-kernel-timing > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc $name rc=$?" >> $OUT/recipe.log
 }

@@ -60,9 +60,15 @@ __global__ void __launch_bounds__(256, 2) ub_bwd_single(KArgs a, int n_tiles) {
   ode_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, gridDim.x * 4, 0, n_tiles, blockIdx.x);
 }
 template <class C, bool DROP>
+__global__ void __launch_bounds__(256, 2) ub_bwd2_single(KArgs a, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdSingleLds<C>::FLOATS];
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  ode2_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, gridDim.x * 4, 0, n_tiles, blockIdx.x);
+}
+template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) ub_fwd_split(KArgs a, int n_tiles) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS];
-  ode_fwd_split<C, DROP, false>(a, (lfp)lds_raw, blockIdx.x, gridDim.x, 0, n_tiles);
+  ode_fwd_split<C, DROP, false, true>(a, (lfp)lds_raw, blockIdx.x, gridDim.x, 0, n_tiles);
 }
 template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) ub_bwd_split(KArgs a, int n_tiles) {
@@ -73,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) ub_bwd_split(KArgs a, int n_tiles) {
 template <class C, bool DROP, int WPS>
 __global__ void __launch_bounds__(256, WPS) ub_fwd2_single(KArgs a, int n_tiles) {
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  ode2_fwd_single<C, DROP, false>(a, threadIdx.x & 63, wave, gridDim.x * 4, 0, n_tiles);
+  ode2_fwd_single<C, DROP, false, true>(a, threadIdx.x & 63, wave, gridDim.x * 4, 0, n_tiles);
 }
 
 template <class C, bool DROP, int WPS>
@@ -103,6 +109,18 @@ __global__ void __launch_bounds__(512, 2) ub_bwdx8(KArgs a, int n_tiles) {
   const int wave = blockIdx.x * 8 + (threadIdx.x >> 6);
   odex_bwd_wg<C, DROP, 8>(a, (char __attribute__((address_space(3)))*)ub_lds8, wave, gridDim.x * 8, 0, n_tiles,
                           blockIdx.x);
+}
+
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256, 2) ub_bwd3_single(KArgs a, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdActLds<C>::FLOATS];
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, gridDim.x * 4, 0, n_tiles, blockIdx.x);
+}
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256, 2) ub_bwd3_split(KArgs a, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdSplitLds<C>::FLOATS];
+  ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, gridDim.x, 0, n_tiles, blockIdx.x);
 }
 
 struct Problem {
@@ -160,6 +178,13 @@ static Problem make_problem(int n_tiles, int L, bool drop) {
   std::vector<long long> base(L + 4);
   for (int s = 0; s < L + 4; ++s) base[s] = (long long)s * n;
   long long* dl = dalloc<long long>(L + 4); h2d(dl, base); a.base_s = dl;
+  {
+    std::vector<long long> b16(L + 2);
+    const long long n16 = (n + 15) / 16 * 16;
+    for (int s = 0; s < L + 2; ++s) b16[s] = (long long)s * n16;
+    long long* d16 = dalloc<long long>(L + 2); h2d(d16, b16); a.base16_s = d16;
+    a.act = dalloc<float>((size_t)n16 * L * 8 * MF<C>::Q1);
+  }
   a.K = L;
   a.n_times = 1;
   p.d_traj = dalloc<float>((size_t)n * L * C::H);
@@ -329,6 +354,39 @@ int main(int argc, char** argv) {
           return g;
         };
         std::vector<float> ref_g = slab_sum(blocks);
+        {
+          CK(hipMemset(p.d_slab, 0, (size_t)4096 * C::P * sizeof(float)));
+          CK(hipMemset(p.d_lamstart, 0, (size_t)p.n_items * C::H * sizeof(float)));
+          float msb = drop ? time_ms([&] { ub_bwd2_single<C, true><<<blocks, 256>>>(p.a, p.n_tiles); }, reps)
+                           : time_ms([&] { ub_bwd2_single<C, false><<<blocks, 256>>>(p.a, p.n_tiles); }, reps);
+          char exb[192];
+          snprintf(exb, sizeof exb, ", \"rel_l2_lam\": %.3e, \"rel_l2_grad\": %.3e",
+                   rel_l2(d2h(p.d_lamstart, (size_t)p.n_items * C::H), ref_lam), rel_l2(slab_sum(blocks), ref_g));
+          report(drop ? "bwd2.drop" : "bwd2", p, blocks, wps, msb, 241, exb);
+        }
+        {   // stored activations: forward (scaled one-wave role) stores, backward loads
+          if (drop) ub_fwd2_single<C, true, 2><<<blocks, 256>>>(p.a, p.n_tiles);
+          else ub_fwd2_single<C, false, 2><<<blocks, 256>>>(p.a, p.n_tiles);
+          CK(hipMemset(p.d_slab, 0, (size_t)4096 * C::P * sizeof(float)));
+          CK(hipMemset(p.d_lamstart, 0, (size_t)p.n_items * C::H * sizeof(float)));
+          float msb = drop ? time_ms([&] { ub_bwd3_single<C, true><<<blocks, 256>>>(p.a, p.n_tiles); }, reps)
+                           : time_ms([&] { ub_bwd3_single<C, false><<<blocks, 256>>>(p.a, p.n_tiles); }, reps);
+          char exb[192];
+          snprintf(exb, sizeof exb, ", \"rel_l2_lam\": %.3e, \"rel_l2_grad\": %.3e",
+                   rel_l2(d2h(p.d_lamstart, (size_t)p.n_items * C::H), ref_lam), rel_l2(slab_sum(blocks), ref_g));
+          report(drop ? "bwd3.drop" : "bwd3", p, blocks, wps, msb, 173, exb);
+          // four-wave role: forward split stores, backward split loads (one tile per block)
+          const int nbs = 512;
+          if (drop) ub_fwd_split<C, true><<<nbs, 256>>>(p.a, p.n_tiles);
+          else ub_fwd_split<C, false><<<nbs, 256>>>(p.a, p.n_tiles);
+          CK(hipMemset(p.d_slab, 0, (size_t)4096 * C::P * sizeof(float)));
+          CK(hipMemset(p.d_lamstart, 0, (size_t)p.n_items * C::H * sizeof(float)));
+          msb = drop ? time_ms([&] { ub_bwd3_split<C, true><<<nbs, 256>>>(p.a, p.n_tiles); }, reps)
+                     : time_ms([&] { ub_bwd3_split<C, false><<<nbs, 256>>>(p.a, p.n_tiles); }, reps);
+          snprintf(exb, sizeof exb, ", \"rel_l2_lam\": %.3e, \"rel_l2_grad\": %.3e",
+                   rel_l2(d2h(p.d_lamstart, (size_t)p.n_items * C::H), ref_lam), rel_l2(slab_sum(nbs), ref_g));
+          report(drop ? "bwd3.split.drop" : "bwd3.split", p, nbs, 2, msb, 173, exb, 1024);
+        }
         CK(hipMemset(p.d_slab, 0, (size_t)4096 * C::P * sizeof(float)));
         CK(hipMemset(p.d_lamstart, 0, (size_t)p.n_items * C::H * sizeof(float)));
         const int nb = CUS;
@@ -363,6 +421,16 @@ int main(int argc, char** argv) {
         snprintf(ex, sizeof ex, ", \"rel_l2_lam\": %.3e, \"rel_l2_grad\": %.3e, \"lds_bytes\": %zu",
                  rel_l2(d2h(p.d_lamstart, (size_t)p.n_items * C::H), ref_lam), rel_l2(slab_sum(nb), ref_g), lds8);
         report(drop ? "bwdx8.drop" : "bwdx8", p, nb, 2, ms4, 300, ex, 1024);
+#ifdef NJ_XSTAMP
+        {
+          std::vector<unsigned long long> tsv(11);
+          CK(hipMemcpy(tsv.data(), p.a.g_h0, 11 * 8, hipMemcpyDeviceToHost));
+          printf("{\"case\": \"bwdx8.stamps%s\", \"steps\": %llu, \"cycles_per_step_by_phase\": [", drop ? ".drop" : "", tsv[10]);
+          double tot = 0;
+          for (int i = 0; i < 10; ++i) { printf("%s%.0f", i ? ", " : "", (double)tsv[i] / tsv[10]); tot += (double)tsv[i] / tsv[10]; }
+          printf("], \"sum\": %.0f, \"phases\": \"L1 | act1+split | L2 | act2+split+img | dW3 | W3T+d2+split | dW2 | W2T+d1+split | dW1 | W1T+lam\"}\n", tot);
+        }
+#endif
       }
     }
     // ---- four waves per tile (latency form)
@@ -374,6 +442,9 @@ int main(int argc, char** argv) {
       ms = drop ? time_ms([&] { ub_bwd_split<C, true><<<1, 256>>>(p.a, 1); }, reps)
                 : time_ms([&] { ub_bwd_split<C, false><<<1, 256>>>(p.a, 1); }, reps);
       report(drop ? "bwd4.lone.drop" : "bwd4.lone", p, 1, 0, ms, 241, "", 1);
+      ms = drop ? time_ms([&] { ub_bwd3_split<C, true><<<1, 256>>>(p.a, 1); }, reps)
+                : time_ms([&] { ub_bwd3_split<C, false><<<1, 256>>>(p.a, 1); }, reps);
+      report(drop ? "bwd3split.lone.drop" : "bwd3split.lone", p, 1, 0, ms, 173, "", 1);
     }
   }
   return 0;
