@@ -313,15 +313,21 @@ def main():
             # ALGORITHMIC work of one launch of the ODE kernels, per
             # Euler step of one path.  STRICT: the network is 13.50 + 50.50 +
             # 50.10 = 3 650 MAC forward, its exact backward 2x that = 7 300 MAC = 14 600 flop.
-            # WITH RECOMPUTE (what the backward kernel executes of useful work, biases as one
-            # MAC per output): recompute L1+L2 3 250 + transposed products 3 500 + weight-gradient
-            # outer products 3 760 = 10 510 MAC.  Tile padding (50->64, 10->16) is never counted.
+            # EXECUTED (useful work the kernel really issues, biases as one MAC per output):
+            # forward 3 760; the backward reads the forward's stored hidden activations, so it
+            # issues the transposed products 3 500 + the weight-gradient outer products 3 760 =
+            # 7 260 MAC and recomputes nothing (round 1 recomputed L1+L2: 10 510).  Tile padding
+            # (50->64, 10->16) is never counted.
             strict = {'k_ode_bwd_mixed': 7300, 'k_ode_bwd_mfma': 7300, 'k_ode_bwd_items': 7300,
                       'k_ode_fwd_mixed': 3650, 'k_ode_fwd_mfma': 3650, 'k_ode_fwd_items': 3650}.get(dom)
-            executed = {'k_ode_bwd_mixed': 10510, 'k_ode_bwd_mfma': 10510,
+            executed = {'k_ode_bwd_mixed': 7260, 'k_ode_bwd_mfma': 7260,
                         'k_ode_bwd_items': 10510 + 510, 'k_ode_fwd_mixed': 3760,
                         'k_ode_fwd_mfma': 3760, 'k_ode_fwd_items': 3760}.get(dom)
-            bytes_ = euler_steps * H * 4 + n_obs * (2 * H * 4 + 32)
+            # HBM bytes one launch must move: per Euler step of one path the state checkpoint
+            # (H floats) and the stored activation record (8 x ceil(W/4) floats, unmasked
+            # train steps only); per observation row the jump state in and out + its item record.
+            act_rec = 8 * ((W + 3) // 4) * 4
+            bytes_ = euler_steps * (H * 4 + act_rec) + n_obs * (2 * H * 4 + 32)
             if strict is not None:
                 tf_s = 2.0 * strict * euler_steps / (dom_ms * 1e-3) / 1e12
                 tf_e = 2.0 * executed * euler_steps / (dom_ms * 1e-3) / 1e12
@@ -331,16 +337,16 @@ def main():
                     'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
                     'frac': round(tf_s / FP32_MFMA_PEAK_TF, 5),
                     'frac_strict': round(tf_s / FP32_MFMA_PEAK_TF, 5),
-                    'frac_with_recompute': round(tf_e / FP32_MFMA_PEAK_TF, 5),
-                    'achieved_with_recompute': round(tf_e, 3),
+                    'frac_executed': round(tf_e / FP32_MFMA_PEAK_TF, 5),
+                    'achieved_executed': round(tf_e, 3),
                     'traffic': traffic, 'traffic_source': traffic_src,
                     'kernel_ms': round(dom_ms, 5),
                     'algorithmic_flops': int(2 * strict * euler_steps),
                     'executed_useful_flops': int(2 * executed * euler_steps),
                     'note': 'achieved / frac = STRICT algorithmic work (SURVEY 8d: 14 600 flop per '
-                            'Euler step of the backward, 7 300 forward); frac_with_recompute also '
-                            'counts the checkpoint recompute and the bias MACs the kernel really '
-                            'executes.  Peak = dense f32 MFMA = f32 vector peak; on gfx950 '
+                            'Euler step of the backward, 7 300 forward); frac_executed counts the '
+                            'MACs the kernel really issues (7 260 backward on stored activations, '
+                            '3 760 forward with biases).  Peak = dense f32 MFMA = f32 vector peak; on gfx950 '
                             'v_mfma_f32_16x16x4_f32 and the VALU share ONE pipe (measured: '
                             'profiles/r02_pipe_ubench.jsonl), so the tanh / dropout / delta VALU '
                             'work of the kernel spends the same peak (DESIGN.md section 5)'}
@@ -349,8 +355,9 @@ def main():
                     'bound': 'hbm', 'kernel': dom, 'achieved': round(gbs, 3),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 6),
                     'algorithmic_bytes': int(bytes_),
-                    'note': '~330 flop/B: the path is compute bound, the HBM fraction is '
-                            'reported because BASELINE.json asks for it'}
+                    'note': '~32 flop/B with the stored activations (machine balance '
+                            '~20 flop/B): still compute bound; the HBM fraction is reported '
+                            'because BASELINE.json asks for it'}
             tf = flops / (ms * 1e-3) / 1e12
             out['step_flops'] = {'achieved': round(tf, 3), 'peak': FP32_MFMA_PEAK_TF,
                                  'unit': 'TFLOP/s', 'frac': round(tf / FP32_MFMA_PEAK_TF, 5),

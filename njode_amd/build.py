@@ -101,11 +101,13 @@ def build(force=False, jobs=None, verbose=True):
     kernel_deps = [os.path.join(CSRC, n) for n in
                    ('njode_cfg.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
                     'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
-                    'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h')] + [hdr]
+                    'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
+                    'njode_mfma_lock4.h')] + [hdr]
     api_deps = [os.path.join(CSRC, n) for n in
                 ('njode_api.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
                  'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
-                 'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h', 'njode_error.h',
+                 'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
+                 'njode_mfma_lock4.h', 'njode_error.h',
                  '_generated_cfgs.inc')] + [hdr, hdr_self]
     prod_deps = [os.path.join(CSRC, n) for n in ('njode_producer.hip', 'njode_error.h')] + [
         hdr, hdr_prod]

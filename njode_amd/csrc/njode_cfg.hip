@@ -30,6 +30,16 @@ constexpr bool HAS_MFMA_LOCK = C::NH == 2 && !C::RNN && C::W < 64 && C::H <= 64 
 constexpr bool HAS_MFMA_SWEEP =
     HAS_MFMA_LOCK && (!C::MASKED || C::ENC_CASE == 0 || (C::ENC_CASE == 1 && C::D == C::H));
 constexpr bool HAS_SPLIT = HAS_MFMA && SplitOk<C>::value;
+// masked shapes: one tile over the four waves of a block (njode_mfma_lock4.h); NJODE_LOCK4=0
+// keeps the one-wave kernels (maintainer A/B)
+constexpr bool HAS_Q4 = HAS_MFMA_SWEEP && Q4Ok<C>::value;
+static inline bool lock4_on() {
+  static const bool on = [] {
+    const char* e = getenv("NJODE_LOCK4");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 template <bool ON, class CC> struct FragSize {
   static constexpr int ode = 0, enc = 0, dec = 0;
 };
@@ -248,6 +258,12 @@ template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) 
   }
 }
 template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_Q4) {
+    if (!a.want_path && lock4_on()) {
+      k_paths_fwd_q4<CC, DROP><<<cdiv(a.B, 16), 256, 0, st>>>(a);
+      return;
+    }
+  }
   if constexpr (HAS_MFMA_LOCK) k_paths_fwd_mfma<CC, DROP><<<cdiv(a.B, 32), 128, 0, st>>>(a);
 }
 template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, int ode, hipStream_t st) {
@@ -281,7 +297,14 @@ template <class CC, bool DROP> static void lock_bwd_mfma(const KArgs& a, hipStre
                                                                              a.frag_dec);
     {
       ProfScope ps("k_paths_bwd_adj_mfma", st);
-      k_paths_bwd_adj_mfma<CC, DROP><<<cdiv(a.B, 16), 64, 0, st>>>(a);
+      bool q4 = false;
+      if constexpr (HAS_Q4) {
+        if (lock4_on()) {
+          k_paths_bwd_adj_q4<CC, DROP><<<cdiv(a.B, 16), 256, 0, st>>>(a);
+          q4 = true;
+        }
+      }
+      if (!q4) k_paths_bwd_adj_mfma<CC, DROP><<<cdiv(a.B, 16), 64, 0, st>>>(a);
     }
     {
       ProfScope ps("k_ode_dw_pairs_mfma", st);

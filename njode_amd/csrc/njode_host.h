@@ -6,6 +6,7 @@
 #include "njode_lockstep_bwd.h"
 #include "njode_mfma_lockstep.h"
 #include "njode_mfma_split.h"
+#include "njode_mfma_lock4.h"
 
 namespace njode {
 

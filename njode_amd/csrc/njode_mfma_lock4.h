@@ -1,0 +1,795 @@
+// njode_mfma_lock4.h -- the lockstep plan of the MASKED (PhysioNet-shaped) models with one
+// tile of 16 paths spread over the FOUR waves (= four SIMDs) of a 256-thread block.
+//
+// Why: a masked model feeds its own prediction back at every jump (models.py:465-467), so a
+// path is one serial chain of n_steps Euler steps and ~n_obs jumps; physionet_train.py runs
+// 3 000 steps at B = 50, i.e. FOUR tiles on the whole chip.  The one-wave kernels of
+// njode_mfma_lockstep.h issue all 179 (step) / 445 (jump) MFMAs of an evaluation from one
+// SIMD, every A-fragment re-read from LDS / L2 each time, and carry every per-path vector
+// (x, mask, y: 41 floats each) in full in every lane: ~10 us per step forward, ~20 us backward
+// (profiles/r01_config5_bench.jsonl).  Here
+//
+//   * wave w owns output tile w (units 16w .. 16w+15) of every layer of the three networks and
+//     the same slice of every per-path vector (h, x, mask, y, the adjoint, ...): 4 registers
+//     per lane, lane (g, c) = unit 16w + 4r + g of path c;
+//   * its A-fragments are register resident (the launch bound gives a wave the whole 512-entry
+//     register file: 132 fragments forward, 217 in the adjoint sweep);
+//   * a layer's input is all-gathered through an LDS image [unit][path] -- one s_barrier per
+//     exchange, 3 per Euler step forward, 4 in the sweep;
+//   * per-path scalars of the loss are reduced across lane groups and waves in a fixed order.
+//
+// The kernels write exactly the buffers the one-wave kernels write (ltraj, src_row, h_end, y_row,
+// ybj_row, hT, loss_terms; lam_traj, g_y, g_ybj, g_hnew, g_hstart), so pass 2 of the backward
+// (k_ode_dw_pairs_mfma, k_dec_dw_rows_mfma, k_enc_dw_rows_mfma) is unchanged.  Dropout masks are
+// those of the one-wave kernels.  return_path calls stay on k_paths_fwd_mfma.
+#pragma once
+#include "njode_mfma_lockstep.h"
+#include "njode_mfma_split.h"
+
+namespace njode {
+
+template <class C, bool TWO = (C::NH == 2)> struct Q4Ok { static constexpr bool value = false; };
+template <class C> struct Q4Ok<C, true> {
+  static constexpr bool value =
+      C::MASKED && !C::RNN && MF<C>::MT1 == 4 && C::D == C::DO && C::H <= 64 && C::D <= 64 &&
+      MF<C>::MTB1 <= 8 && (C::ENC_CASE == 0 || (C::ENC_CASE == 1 && C::D == C::H)) &&
+      (C::DEC_CASE == 0 || (C::DEC_CASE == 1 && C::DO == C::H));
+};
+
+// the ODE network's fragment table (MF<C>) under the names of MS<>
+template <class C> struct OdeQS {
+  using M = MF<C>;
+  static constexpr int IN = M::IN0, OUT = C::H, W = C::W;
+  static constexpr int Q0 = M::Q0, Q1 = M::Q1, QO = M::QH, QW = M::QW;
+  static constexpr int MT1 = M::MT1, MTO = M::MTH, MTI = M::MTB1;
+  static constexpr int F1 = M::F1, F2 = M::F2, F3 = M::F3, B3 = M::B3, B2 = M::B2, B1 = M::B1;
+};
+
+constexpr int q4_img_rows(int q) { return (4 * q + 15) / 16 * 16; }
+
+// this wave's forward fragments of one network
+template <class S> struct Q4Fwd {
+  float A1[S::Q0], A2[S::Q1], A3[S::Q1];
+  NJ_DEV void load(const float* frag, int w, int lane) {
+    static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
+#pragma unroll
+    for (int q = 0; q < S::Q0; ++q) A1[q] = frag[(S::F1 + w * S::Q0 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < S::Q1; ++q) A2[q] = frag[(S::F2 + w * S::Q1 + q) * 64 + lane];
+    const int wo = w < S::MTO ? w : 0;
+#pragma unroll
+    for (int q = 0; q < S::Q1; ++q) A3[q] = frag[(S::F3 + wo * S::Q1 + q) * 64 + lane];
+  }
+};
+// ... and those of the adjoint sweep: hidden recompute + the three transposed products; the
+// input-gradient tiles w, w + 4, ... (NB1 of them)
+template <class S, int NB1> struct Q4Adj {
+  float A1[S::Q0], A2[S::Q1], B3[S::QO], B2[S::QW], B1[NB1][S::QW];
+  NJ_DEV void load(const float* frag, int w, int lane) {
+    static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
+#pragma unroll
+    for (int q = 0; q < S::Q0; ++q) A1[q] = frag[(S::F1 + w * S::Q0 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < S::Q1; ++q) A2[q] = frag[(S::F2 + w * S::Q1 + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < S::QO; ++q) B3[q] = frag[(S::B3 + w * S::QO + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < S::QW; ++q) B2[q] = frag[(S::B2 + w * S::QW + q) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+      const int t = w + 4 * j < S::MTI ? w + 4 * j : 0;
+#pragma unroll
+      for (int q = 0; q < S::QW; ++q) B1[j][q] = frag[(S::B1 + t * S::QW + q) * 64 + lane];
+    }
+  }
+};
+
+// sum_q A[q] (x) b[q] on two accumulators (halves the dependent chain)
+template <int NQ> NJ_DEV f32x4 q4_dot(const float (&A)[NQ], const float (&b)[NQ]) {
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < NQ; q += 2) {
+    s0 = mfma4(A[q], b[q], s0);
+    if (q + 1 < NQ) s1 = mfma4(A[q + 1], b[q + 1], s1);
+  }
+  return s0 + s1;
+}
+
+// own registers <-> image rows.  q4_put: all four rows (images of >= 64 rows, invalid units carry
+// zeros); q4_put_n: units < N only, at row offset row0
+NJ_DEV void q4_put(lfp X, const float (&v)[4], int g, int c, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) X[(16 * w + 4 * r + g) * IMG_STRIDE + c] = v[r];
+}
+template <int N> NJ_DEV void q4_put_n(lfp X, int row0, const float (&v)[4], int g, int c, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int u = 16 * w + 4 * r + g;
+    if (u < N) X[(row0 + u) * IMG_STRIDE + c] = v[r];
+  }
+}
+template <int N> NJ_DEV void q4_put_n_if(lfp X, int row0, const float (&v)[4], bool on, int g, int c, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int u = 16 * w + 4 * r + g;
+    if (on && u < N) X[(row0 + u) * IMG_STRIDE + c] = v[r];
+  }
+}
+template <int N> NJ_DEV void q4_get_n(lfp X, int row0, float (&v)[4], int g, int c, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int u = 16 * w + 4 * r + g;
+    const float t = X[(row0 + (u < N ? u : 0)) * IMG_STRIDE + c];
+    v[r] = u < N ? t : 0.0f;
+  }
+}
+
+// D-layout register q of a layer input [v (NV units from the image), 1, 0 ...]
+template <int NV, int Q> NJ_DEV float q4_bias_patch(float raw, int g) {
+  const float e0 = 4 * Q + 0 < NV ? raw : (4 * Q + 0 == NV ? 1.0f : 0.0f);
+  const float e1 = 4 * Q + 1 < NV ? raw : (4 * Q + 1 == NV ? 1.0f : 0.0f);
+  const float e2 = 4 * Q + 2 < NV ? raw : (4 * Q + 2 == NV ? 1.0f : 0.0f);
+  const float e3 = 4 * Q + 3 < NV ? raw : (4 * Q + 3 == NV ? 1.0f : 0.0f);
+  return g == 0 ? e0 : (g == 1 ? e1 : (g == 2 ? e2 : e3));
+}
+template <int NV, int NQ, int Q = 0> NJ_DEV void q4_input(lfp X, float (&b)[NQ], int g, int c) {
+  if constexpr (Q < NQ) {
+    const float raw = X[(4 * Q + g) * IMG_STRIDE + c];
+    if constexpr (4 * Q + 3 < NV) b[Q] = raw;
+    else b[Q] = q4_bias_patch<NV, Q>(raw, g);
+    q4_input<NV, NQ, Q + 1>(X, b, g, c);
+  }
+}
+// ... of the ODE network: [tanh(h) (H), tanh(x) (D)] from the image, then tau, t - tau, (t), 1
+template <class C, int U> NJ_DEV float q4_in0_unit(float raw, float tau, float tdiff) {
+  if constexpr (U < C::H + C::D) return raw;
+  else if constexpr (U == C::H + C::D) return tau;
+  else if constexpr (U == C::H + C::D + 1) return tdiff;
+  else if constexpr (C::CURT && U == C::H + C::D + 2) return tau + tdiff;
+  else if constexpr (U == C::ODE_IN) return 1.0f;
+  else return 0.0f;
+}
+template <class C, int Q = 0>
+NJ_DEV void q4_in0(lfp X, float (&b)[MF<C>::Q0], float tau, float tdiff, int g, int c) {
+  if constexpr (Q < MF<C>::Q0) {
+    const float raw = X[(4 * Q + g) * IMG_STRIDE + c];
+    if constexpr (4 * Q + 3 < C::H + C::D) {
+      b[Q] = raw;
+    } else {
+      const float e0 = q4_in0_unit<C, 4 * Q + 0>(raw, tau, tdiff);
+      const float e1 = q4_in0_unit<C, 4 * Q + 1>(raw, tau, tdiff);
+      const float e2 = q4_in0_unit<C, 4 * Q + 2>(raw, tau, tdiff);
+      const float e3 = q4_in0_unit<C, 4 * Q + 3>(raw, tau, tdiff);
+      b[Q] = g == 0 ? e0 : (g == 1 ? e1 : (g == 2 ? e2 : e3));
+    }
+    q4_in0<C, Q + 1>(X, b, tau, tdiff, g, c);
+  }
+}
+
+// hidden activation of the own tile (+ dropout by the own 4 keep bits); the bias unit W is 1
+template <int W, int ACT, bool DROP>
+NJ_DEV void q4_hidden(const f32x4& acc, float (&al)[4], uint32_t keep4, float inv_keep, int g, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = act_f<ACT>(acc[r]);
+    if constexpr (DROP) v = ((keep4 >> r) & 1) ? v * inv_keep : 0.0f;
+    al[r] = v;
+  }
+  if (w == W / 16) al[(W % 16) / 4] = g == W % 4 ? 1.0f : al[(W % 16) / 4];
+}
+template <int W, int ACT, bool DROP>
+NJ_DEV void q4_delta(const f32x4& acc, const float (&al)[4], float (&dl)[4], uint32_t keep4, float inv_keep,
+                     float keepf, int g, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float d;
+    if constexpr (DROP) d = ((keep4 >> r) & 1) ? acc[r] * inv_keep * dact_f<ACT>(al[r] * keepf) : 0.0f;
+    else d = acc[r] * dact_f<ACT>(al[r]);
+    dl[r] = (16 * w + 4 * r + g) < W ? d : 0.0f;   // bias / padding units carry no delta
+  }
+}
+
+// own 4 keep bits of the two hidden layers, from the streams of the one-wave kernels
+template <bool DROP>
+NJ_DEV void q4_row_keep(const KArgs& a, unsigned long long gid, uint32_t tkey, uint32_t net, int g, int w,
+                        uint32_t& k1, uint32_t& k2) {
+  uint32_t f1, f2;
+  row_keep_bits<DROP>(a, gid, tkey, net, g, 16, f1, f2);
+  k1 = (f1 >> (4 * w)) & 15u;
+  k2 = (f2 >> (4 * w)) & 15u;
+}
+template <class C, bool DROP>
+NJ_DEV void q4_ode_keep(const KArgs& a, unsigned long long gid, int k, int g, int w, uint32_t& k1, uint32_t& k2) {
+  k1 = k2 = 0;
+  if constexpr (DROP) {
+    uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1), (uint32_t)k,
+                             NET_ODE);
+    const uint32_t f1 = keep_bits<MF<C>::Q1>(st, a.dc.thr16);
+    const uint32_t f2 = keep_bits<MF<C>::Q1>(st, a.dc.thr16);
+    k1 = (f1 >> (4 * w)) & 15u;
+    k2 = (f2 >> (4 * w)) & 15u;
+  }
+}
+
+// forward of one network: b0 (all units) -> this wave's output tile.  Two exchanges.
+template <class S, int ACT, bool DROP>
+NJ_DEV f32x4 q4_net_fwd(const Q4Fwd<S>& F, lfp XA, lfp XB, const float (&b0)[S::Q0], uint32_t k1, uint32_t k2,
+                        float inv_keep, int g, int c, int w) {
+  f32x4 acc = q4_dot<S::Q0>(F.A1, b0);
+  float al[4], av[S::Q1];
+  q4_hidden<S::W, ACT, DROP>(acc, al, k1, inv_keep, g, w);
+  q4_put(XA, al, g, c, w);
+  block_lds_barrier();
+  split_get<S::Q1>(XA, av, g, c);
+  acc = q4_dot<S::Q1>(F.A2, av);
+  q4_hidden<S::W, ACT, DROP>(acc, al, k2, inv_keep, g, w);
+  q4_put(XB, al, g, c, w);
+  block_lds_barrier();
+  split_get<S::Q1>(XB, av, g, c);
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  if (w < S::MTO) out = q4_dot<S::Q1>(F.A3, av);
+  return out;
+}
+
+// per-path sums of the own units -> all units (lane groups by shuffle, waves through LDS)
+NJ_DEV void q4_path_sums(lfp LR, float& sa, float& sb, int g, int c, int w) {
+  sa += __shfl_xor(sa, 16);
+  sb += __shfl_xor(sb, 16);
+  sa += __shfl_xor(sa, 32);
+  sb += __shfl_xor(sb, 32);
+  if (g == 0) {
+    LR[(2 * w + 0) * 16 + c] = sa;
+    LR[(2 * w + 1) * 16 + c] = sb;
+  }
+  block_lds_barrier();
+  sa = (LR[0 * 16 + c] + LR[2 * 16 + c]) + (LR[4 * 16 + c] + LR[6 * 16 + c]);
+  sb = (LR[1 * 16 + c] + LR[3 * 16 + c]) + (LR[5 * 16 + c] + LR[7 * 16 + c]);
+}
+
+template <class C> struct Q4Lds {
+  using ES = typename EncS<C>::type;
+  static constexpr int INR = q4_img_rows(MF<C>::Q0) > q4_img_rows(ES::Q0) ? q4_img_rows(MF<C>::Q0)
+                                                                           : q4_img_rows(ES::Q0);
+  static constexpr int IN_FL = INR * IMG_STRIDE;
+  // XA, XB, XD, HN (64 rows), IN, EI, LX (INR rows), LR
+  static constexpr int FLOATS = 4 * XFLOATS + 3 * IN_FL + 8 * 16;
+};
+
+// =====================================================================================
+// forward
+// =====================================================================================
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
+  using M = MF<C>;
+  using OS = OdeQS<C>;
+  using ES = typename EncS<C>::type;
+  using DS = typename DecS<C>::type;
+  using L = Q4Lds<C>;
+  constexpr int D = C::D, H = C::H, DO = C::DO;
+  __shared__ __attribute__((aligned(16))) float lds_raw[L::FLOATS];
+  lfp XA = (lfp)lds_raw, XB = XA + XFLOATS, HN = XB + 2 * XFLOATS, IN = HN + XFLOATS, EI = IN + L::IN_FL,
+      LR = EI + 2 * L::IN_FL;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < L::FLOATS; i += 256) lds_raw[i] = 0.0f;
+  Q4Fwd<OS> Fo;
+  Q4Fwd<ES> Fe;
+  Q4Fwd<DS> Fd;
+  Fo.load(a.frag, w, lane);
+  Fe.load(a.frag_enc, w, lane);
+  Fd.load(a.frag_dec, w, lane);
+  __syncthreads();
+
+  const bool LOSS = a.want_loss != 0, SAVE = a.save_traj != 0;
+  const int b0i = blockIdx.x * 16 + c;
+  const bool valid = b0i < a.B;
+  const int b = valid ? b0i : a.B - 1;
+  const unsigned long long gid = a.gid0 + b;
+  float* const trash = a.trash + threadIdx.x;
+  const int __attribute__((address_space(4)))* kjump =
+      (const int __attribute__((address_space(4)))*)(unsigned long long)a.k_jump;
+  const cfp sdt = as_cfp(a.step_dt), stt = as_cfp(a.step_t), tf = as_cfp(a.time_f32);
+  int uo[4];   // the own units
+#pragma unroll
+  for (int r = 0; r < 4; ++r) uo[r] = 16 * w + 4 * r + g;
+
+  // readout of the state whose tanh is in image `TH` rows [0, H): this wave's tile of y
+  auto readout = [&](lfp TH, const float (&hq)[4], uint32_t tkey, uint32_t net, float (&y)[4]) {
+    float b0d[DS::Q0];
+    q4_input<H, DS::Q0>(TH, b0d, g, c);
+    uint32_t k1, k2;
+    q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
+    const f32x4 out = q4_net_fwd<DS, C::ACT, DROP>(Fd, XA, XB, b0d, k1, k2, a.dc.inv_keep, g, c, w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = out[r];
+      if constexpr (C::DEC_CASE == 1) v += hq[r];
+      y[r] = uo[r] < DO ? v : 0.0f;
+    }
+  };
+  // encoder of [tanh(xin), mask] staged in EI: this wave's tile of the new state
+  auto encode = [&](const float (&xin)[4], uint32_t tkey, float (&hq)[4]) {
+    float b0e[ES::Q0];
+    q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
+    uint32_t k1, k2;
+    q4_row_keep<DROP>(a, gid, tkey, NET_ENC, g, w, k1, k2);
+    const f32x4 out = q4_net_fwd<ES, C::ACT, DROP>(Fe, XA, XB, b0e, k1, k2, a.dc.inv_keep, g, c, w);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = out[r];
+      if constexpr (C::ENC_CASE == 1) v += xin[r];
+      hq[r] = uo[r] < H ? v : 0.0f;
+    }
+  };
+
+  // ---- initial state: h = encoder(start_X, mask = 0) ----------------------------------------
+  float h[4], th[4], txo[4], xs[4], zero4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = a.start_X[(size_t)b * D + (uo[r] < D ? uo[r] : 0)];
+    xs[r] = uo[r] < D ? v : 0.0f;
+    txo[r] = tanh_f(xs[r]);
+  }
+  q4_put_n<D>(EI, 0, txo, g, c, w);
+  if constexpr (C::MASKED) q4_put_n<D>(EI, D, zero4, g, c, w);
+  q4_put_n<D>(IN, H, txo, g, c, w);
+  block_lds_barrier();
+  encode(xs, TKEY_START, h);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) th[r] = tanh_f(h[r]);
+  q4_put_n<H>(IN, 0, th, g, c, w);
+  block_lds_barrier();
+
+  float tau = 0.0f, loss_acc = 0.0f;
+  int cur = a.first_j[b];
+  int next_i = a.n_obs > 0 ? a.t_of_row[a.row_by_path[cur >= 0 ? cur : 0]] : 0;
+  next_i = cur >= 0 ? next_i : 0x7fffffff;
+  int src = -1;
+
+  int i = 0;
+  for (int k = 0;; ++k) {
+    while (i < a.n_times && kjump[i] == k) {
+      const bool has = valid && next_i == i;
+      if (__any(has)) {   // the same decision in all four waves
+        const int r_ = has ? a.row_by_path[cur >= 0 ? cur : 0] : 0;
+        float ybj[4], yn[4], x[4], m[4], xin[4], txin[4], hn[4], thn[4];
+        if (SAVE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* dst = (has && uo[r] < H) ? a.h_end + (size_t)r_ * H + uo[r] : trash;
+            *dst = h[r];
+          }
+        }
+        readout(IN, h, (uint32_t)k, NET_DEC_BJ, ybj);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = uo[r] < D ? uo[r] : 0;
+          const float xv = a.X[(size_t)r_ * D + u];
+          x[r] = uo[r] < D ? xv : 0.0f;
+          if constexpr (C::MASKED) {
+            const float mv = a.M[(size_t)r_ * D + u];
+            m[r] = uo[r] < D ? mv : 0.0f;
+            xin[r] = x[r] * m[r] + (1.0f - m[r]) * ybj[r];
+          } else {
+            m[r] = uo[r] < D ? 1.0f : 0.0f;
+            xin[r] = x[r];
+          }
+          txin[r] = tanh_f(xin[r]);
+        }
+        q4_put_n<D>(EI, 0, txin, g, c, w);
+        if constexpr (C::MASKED) q4_put_n<D>(EI, D, m, g, c, w);
+        block_lds_barrier();
+        encode(xin, (uint32_t)k, hn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) thn[r] = tanh_f(hn[r]);
+        q4_put_n<H>(HN, 0, thn, g, c, w);
+        block_lds_barrier();
+        readout(HN, hn, (uint32_t)k, NET_DEC, yn);
+        if (LOSS) {   // compute_loss (models.py:76-110) of this row, reduced over all units
+          float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = x[r] - yn[r];
+            const float f = a.loss_easy ? (ybj[r] - x[r]) : (ybj[r] - yn[r]);
+            sa = fmaf(m[r] * e, e, sa);
+            sb = fmaf(m[r] * f, f, sb);
+          }
+          q4_path_sums(LR, sa, sb, g, c, w);
+          const float scale = a.inv_batch * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
+          const float na = sqrtf(sa + 1e-10f), nb = sqrtf(sb + 1e-10f);
+          const float ca = a.loss_easy ? a.weight : 2.0f * a.weight;
+          const float cb = a.loss_easy ? (1.0f - a.weight) : 2.0f * (1.0f - a.weight);
+          const float s = ca * na + cb * nb;
+          loss_acc += has ? s * s * scale : 0.0f;
+        }
+        if (SAVE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool on = has && uo[r] < DO;
+            float* d1 = on ? a.y_row + (size_t)r_ * DO + uo[r] : trash;
+            float* d2 = on ? a.ybj_row + (size_t)r_ * DO + uo[r] : trash;
+            *d1 = yn[r];
+            *d2 = ybj[r];
+          }
+        }
+        // commit for the paths that have an observation (models.py:463-489)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = has ? hn[r] : h[r];
+          th[r] = has ? thn[r] : th[r];
+          const float nt = tanh_f(C::MASKED ? yn[r] : x[r]);
+          txo[r] = has ? nt : txo[r];
+        }
+        q4_put_n<H>(IN, 0, th, g, c, w);
+        q4_put_n<D>(IN, H, txo, g, c, w);
+        block_lds_barrier();
+        const float tnew = tf[i];
+        tau = has ? tnew : tau;
+        src = has ? r_ : src;
+        const int cn = cur + 1;
+        const int cc = cn < a.n_obs ? cn : 0;
+        const int nt_ = a.t_of_row[a.row_by_path[cc]];
+        const int nexti2 = (cn < a.n_obs && a.path_sorted[cc] == b) ? nt_ : 0x7fffffff;
+        cur = has ? cn : cur;
+        next_i = has ? nexti2 : next_i;
+      }
+      ++i;
+    }
+    if (SAVE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* dst = (valid && uo[r] < H) ? a.ltraj + ((size_t)k * a.B + b) * H + uo[r] : trash;
+        *dst = h[r];
+      }
+      if (valid && w == 0 && g == 0 && k < a.K) a.src_row[(size_t)k * a.B + b] = src;
+    }
+    if (k >= a.K) break;
+    {
+      const float dt = sdt[k], t = stt[k];
+      float b0[M::Q0];
+      q4_in0<C>(IN, b0, tau, t - tau, g, c);
+      uint32_t k1, k2;
+      q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
+      const f32x4 out = q4_net_fwd<OS, C::ACT, DROP>(Fo, XA, XB, b0, k1, k2, a.dc.inv_keep, g, c, w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        h[r] = uo[r] < H ? fmaf(dt, out[r], h[r]) : 0.0f;
+        th[r] = tanh_f(h[r]);
+      }
+      q4_put_n<H>(IN, 0, th, g, c, w);
+      block_lds_barrier();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* dst = (valid && uo[r] < H) ? a.hT + (size_t)b * H + uo[r] : trash;
+    *dst = h[r];
+  }
+  if (LOSS && valid && w == 0 && g == 0) a.loss_terms[b] = loss_acc;
+}
+
+// =====================================================================================
+// adjoint sweep (pass 1 of the backward)
+// =====================================================================================
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
+  using M = MF<C>;
+  using OS = OdeQS<C>;
+  using ES = typename EncS<C>::type;
+  using DS = typename DecS<C>::type;
+  using L = Q4Lds<C>;
+  constexpr int D = C::D, H = C::H, DO = C::DO;
+  constexpr int NB1 = (M::MTB1 + 3) / 4;   // in0 gradient tiles per wave
+  static_assert((D + 15) / 16 <= 4 && DS::MTI <= 4, "one input-gradient tile per wave for the row networks");
+  __shared__ __attribute__((aligned(16))) float lds_raw[L::FLOATS];
+  lfp XA = (lfp)lds_raw, XB = XA + XFLOATS, XD = XB + XFLOATS, HN = XD + XFLOATS, IN = HN + XFLOATS,
+      EI = IN + L::IN_FL, LX = EI + L::IN_FL, LR = LX + L::IN_FL;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < L::FLOATS; i += 256) lds_raw[i] = 0.0f;
+  Q4Adj<OS, NB1> Fo;
+  Q4Adj<ES, 1> Fe;
+  Q4Adj<DS, 1> Fd;
+  Fo.load(a.frag, w, lane);
+  Fe.load(a.frag_enc, w, lane);
+  Fd.load(a.frag_dec, w, lane);
+  __syncthreads();
+
+  const int b0i = blockIdx.x * 16 + c;
+  const bool valid = b0i < a.B;
+  const int b = valid ? b0i : a.B - 1;
+  const unsigned long long gid = a.gid0 + b;
+  float* const trash = a.trash + threadIdx.x;
+  const int __attribute__((address_space(4)))* kjump =
+      (const int __attribute__((address_space(4)))*)(unsigned long long)a.k_jump;
+  const cfp sdt = as_cfp(a.step_dt), stt = as_cfp(a.step_t);
+  int uo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) uo[r] = 16 * w + 4 * r + g;
+
+  float lam[4] = {0.f, 0.f, 0.f, 0.f};   // adjoint of h, own units
+  float lx[NB1][4];                      // gradient w.r.t. the ODE input, in0 tiles w, w + 4, ...
+#pragma unroll
+  for (int j = 0; j < NB1; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lx[j][r] = 0.0f;
+  int src = a.last_row[b];
+  int src_i = src >= 0 ? a.t_of_row[src] : -1;
+  float tau = 0.0f;
+  // last_X / tau of the segment that follows row `srow` (or the start value): image rows H + u
+  auto load_source = [&](int srow, bool on) {
+    const int sv = srow >= 0 ? srow : 0;
+    const float* xp = srow >= 0 ? (C::MASKED ? a.y_row + (size_t)sv * DO : a.X + (size_t)sv * D)
+                                : a.start_X + (size_t)b * D;
+    float tx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tx[r] = tanh_f(xp[uo[r] < D ? uo[r] : 0]);
+    q4_put_n_if<D>(IN, H, tx, on, g, c, w);
+    const float tsrc = a.n_obs > 0 ? a.time_f32[a.t_of_row[sv]] : 0.0f;
+    tau = on ? (srow >= 0 ? tsrc : 0.0f) : tau;
+  };
+  load_source(src, true);
+
+  // adjoint of y = readout(hq) w.r.t. hq: own tile of dh from the own tile of dy
+  auto dec_adj = [&](const float (&hq)[4], const float (&dy)[4], uint32_t tkey, uint32_t net, float (&dh)[4]) {
+    float thq[4], b0d[DS::Q0], a1l[4], a2l[4], dl[4], av[DS::Q1], dq[DS::QO], dv[DS::QW];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) thq[r] = tanh_f(hq[r]);
+    q4_put_n<H>(HN, 0, thq, g, c, w);
+    q4_put(XD, dy, g, c, w);
+    block_lds_barrier();
+    q4_input<H, DS::Q0>(HN, b0d, g, c);
+    uint32_t k1, k2;
+    q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
+    f32x4 acc = q4_dot<DS::Q0>(Fd.A1, b0d);
+    q4_hidden<DS::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
+    q4_put(XA, a1l, g, c, w);
+    block_lds_barrier();
+    split_get<DS::Q1>(XA, av, g, c);
+    acc = q4_dot<DS::Q1>(Fd.A2, av);
+    q4_hidden<DS::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
+    split_get<DS::QO>(XD, dq, g, c);
+    acc = q4_dot<DS::QO>(Fd.B3, dq);
+    q4_delta<DS::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
+    q4_put(XB, dl, g, c, w);
+    block_lds_barrier();
+    split_get<DS::QW>(XB, dv, g, c);
+    acc = q4_dot<DS::QW>(Fd.B2, dv);
+    q4_delta<DS::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
+    q4_put(XA, dl, g, c, w);
+    block_lds_barrier();
+    split_get<DS::QW>(XA, dv, g, c);
+    f32x4 din = {0.f, 0.f, 0.f, 0.f};
+    if (w < DS::MTI) din = q4_dot<DS::QW>(Fd.B1[0], dv);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = din[r] * (1.0f - thq[r] * thq[r]);
+      if constexpr (C::DEC_CASE == 1) v += dy[r];
+      dh[r] = uo[r] < H ? v : 0.0f;
+    }
+  };
+
+  float h_n[4];   // state before step k, loaded one step ahead
+  auto fetch_h = [&](int k, float (&hh)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = a.ltraj[((size_t)k * a.B + b) * H + (uo[r] < H ? uo[r] : 0)];
+      hh[r] = uo[r] < H ? v : 0.0f;
+    }
+  };
+  if (a.K > 0) fetch_h(a.K - 1, h_n);
+
+  int i = a.n_times - 1;
+  for (int k = a.K; k >= 0; --k) {
+    if (k < a.K) {
+      // ---- reverse Euler step k
+      float th[4], d3[4], b0[M::Q0], a1l[4], a2l[4], dl[4], av[M::Q1], dq[M::QH], dv[M::QW];
+      const float dt = sdt[k], t = stt[k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        th[r] = uo[r] < H ? tanh_f(h_n[r]) : 0.0f;
+        d3[r] = dt * lam[r];
+      }
+      if (k > 0) fetch_h(k - 1, h_n);
+      q4_put_n<H>(IN, 0, th, g, c, w);
+      q4_put(XD, d3, g, c, w);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* dst = (valid && uo[r] < H) ? a.lam_traj + ((size_t)k * a.B + b) * H + uo[r] : trash;
+        *dst = lam[r];
+      }
+      block_lds_barrier();                                   // (1) in0 and delta3 of all tiles
+      q4_in0<C>(IN, b0, tau, t - tau, g, c);
+      uint32_t k1, k2;
+      q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
+      f32x4 acc = q4_dot<M::Q0>(Fo.A1, b0);
+      q4_hidden<C::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
+      q4_put(XA, a1l, g, c, w);
+      block_lds_barrier();                                   // (2) a1
+      split_get<M::Q1>(XA, av, g, c);
+      acc = q4_dot<M::Q1>(Fo.A2, av);
+      q4_hidden<C::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
+      split_get<M::QH>(XD, dq, g, c);
+      acc = q4_dot<M::QH>(Fo.B3, dq);
+      q4_delta<C::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
+      q4_put(XB, dl, g, c, w);
+      block_lds_barrier();                                   // (3) delta2
+      split_get<M::QW>(XB, dv, g, c);
+      acc = q4_dot<M::QW>(Fo.B2, dv);
+      q4_delta<C::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
+      q4_put(XA, dl, g, c, w);
+      block_lds_barrier();                                   // (4) delta1
+      split_get<M::QW>(XA, dv, g, c);
+      // in0 units: [h (H), x (D), ...]; both are tanh'd inputs whose values sit in the image
+#pragma unroll
+      for (int j = 0; j < NB1; ++j) {
+        if (w + 4 * j < M::MTB1) {
+          const f32x4 din = q4_dot<M::QW>(Fo.B1[j], dv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = 16 * (w + 4 * j) + 4 * r + g;
+            // (rows < H are being rewritten by faster waves for the next step: the own register)
+            const float tx_ = IN[(u < H ? H : u) * IMG_STRIDE + c];
+            const float tv = (j == 0 && u < H) ? th[r] : tx_;
+            const float gq = din[r] * (1.0f - tv * tv);
+            if (j == 0) lam[r] += u < H ? gq : 0.0f;
+            if constexpr (C::MASKED) lx[j][r] += (u >= H && u < H + D) ? gq : 0.0f;
+          }
+        }
+      }
+    }
+    // ---- reverse the jump applied right before step k
+    while (i >= 0 && kjump[i] == k) {
+      const bool has = valid && src >= 0 && src_i == i;
+      if (__any(has)) {
+        const int r_ = has ? src : 0;
+        float hn[4], hp[4], x[4], m[4], y[4], ybj[4], dy[4], dybj[4], dh[4], lam_hn[4], lam_new[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int uh = uo[r] < H ? uo[r] : 0, ud = uo[r] < D ? uo[r] : 0;
+          const float v0 = a.ltraj[((size_t)k * a.B + b) * H + uh], v1 = a.h_end[(size_t)r_ * H + uh];
+          const float v2 = a.X[(size_t)r_ * D + ud], v4 = a.y_row[(size_t)r_ * DO + ud],
+                      v5 = a.ybj_row[(size_t)r_ * DO + ud];
+          hn[r] = uo[r] < H ? v0 : 0.0f;
+          hp[r] = uo[r] < H ? v1 : 0.0f;
+          x[r] = uo[r] < D ? v2 : 0.0f;
+          y[r] = uo[r] < D ? v4 : 0.0f;
+          ybj[r] = uo[r] < D ? v5 : 0.0f;
+          if constexpr (C::MASKED) {
+            const float v3 = a.M[(size_t)r_ * D + ud];
+            m[r] = uo[r] < D ? v3 : 0.0f;
+          } else {
+            m[r] = uo[r] < D ? 1.0f : 0.0f;
+          }
+        }
+        if constexpr (C::MASKED) {   // stage lx for the gather below (own in0 tiles -> rows)
+#pragma unroll
+          for (int j = 0; j < NB1; ++j)
+            if (w + 4 * j < M::MTB1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) LX[(16 * (w + 4 * j) + 4 * r + g) * IMG_STRIDE + c] = lx[j][r];
+            }
+        }
+        // gradient of compute_loss at this row
+        {
+          float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = x[r] - y[r];
+            const float f = a.loss_easy ? (ybj[r] - x[r]) : (ybj[r] - y[r]);
+            sa = fmaf(m[r] * e, e, sa);
+            sb = fmaf(m[r] * f, f, sb);
+          }
+          q4_path_sums(LR, sa, sb, g, c, w);   // (its barrier also publishes LX)
+          const float scale = a.inv_batch * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
+          const float na = sqrtf(sa + 1e-10f), nb = sqrtf(sb + 1e-10f);
+          const float ca = a.loss_easy ? a.weight : 2.0f * a.weight;
+          const float cb = a.loss_easy ? (1.0f - a.weight) : 2.0f * (1.0f - a.weight);
+          const float s = ca * na + cb * nb;
+          const float gg = 2.0f * s * scale;
+          const float ga = gg * ca / na, gb = gg * cb / nb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = x[r] - y[r];
+            if (a.loss_easy) {
+              const float f = ybj[r] - x[r];
+              dy[r] = -ga * m[r] * e;
+              dybj[r] = gb * m[r] * f;
+            } else {
+              const float f = ybj[r] - y[r];
+              dy[r] = -ga * m[r] * e - gb * m[r] * f;
+              dybj[r] = gb * m[r] * f;
+            }
+          }
+        }
+        if constexpr (C::MASKED) {   // last_X <- Y: the later segment's input gradient
+          float lxo[4];
+          q4_get_n<D>(LX, H, lxo, g, c, w);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dy[r] += lxo[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = (has && uo[r] < DO) ? a.g_y + (size_t)r_ * DO + uo[r] : trash;
+          *dst = dy[r];
+        }
+        dec_adj(hn, dy, (uint32_t)k, NET_DEC, dh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lam_hn[r] = lam[r] + dh[r];
+          float* dst = (has && uo[r] < H) ? a.g_hnew + (size_t)r_ * H + uo[r] : trash;
+          *dst = lam_hn[r];
+        }
+        if constexpr (C::MASKED) {
+          // h_new = encoder(x_in, M), x_in = X M + (1 - M) y_bj
+          float xin[4], txin[4], b0e[ES::Q0], a1l[4], a2l[4], dl[4], av[ES::Q1], dq[ES::QO], dv[ES::QW];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            xin[r] = x[r] * m[r] + (1.0f - m[r]) * ybj[r];
+            txin[r] = tanh_f(xin[r]);
+          }
+          q4_put_n<D>(EI, 0, txin, g, c, w);
+          q4_put_n<D>(EI, D, m, g, c, w);
+          q4_put(XD, lam_hn, g, c, w);
+          block_lds_barrier();
+          q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
+          uint32_t k1, k2;
+          q4_row_keep<DROP>(a, gid, (uint32_t)k, NET_ENC, g, w, k1, k2);
+          f32x4 acc = q4_dot<ES::Q0>(Fe.A1, b0e);
+          q4_hidden<ES::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
+          q4_put(XA, a1l, g, c, w);
+          block_lds_barrier();
+          split_get<ES::Q1>(XA, av, g, c);
+          acc = q4_dot<ES::Q1>(Fe.A2, av);
+          q4_hidden<ES::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
+          split_get<ES::QO>(XD, dq, g, c);
+          acc = q4_dot<ES::QO>(Fe.B3, dq);
+          q4_delta<ES::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
+          q4_put(XB, dl, g, c, w);
+          block_lds_barrier();
+          split_get<ES::QW>(XB, dv, g, c);
+          acc = q4_dot<ES::QW>(Fe.B2, dv);
+          q4_delta<ES::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
+          q4_put(XA, dl, g, c, w);
+          block_lds_barrier();
+          split_get<ES::QW>(XA, dv, g, c);
+          f32x4 din = {0.f, 0.f, 0.f, 0.f};
+          if (w < (D + 15) / 16) din = q4_dot<ES::QW>(Fe.B1[0], dv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = din[r] * (1.0f - txin[r] * txin[r]);
+            if constexpr (C::ENC_CASE == 1) v += lam_hn[r];
+            const float dx = uo[r] < D ? v : 0.0f;
+            dybj[r] += dx * (1.0f - m[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* dst = (has && uo[r] < DO) ? a.g_ybj + (size_t)r_ * DO + uo[r] : trash;
+          *dst = dybj[r];
+        }
+        dec_adj(hp, dybj, (uint32_t)k, NET_DEC_BJ, lam_new);
+        // commit for the paths that have this observation
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lam[r] = has ? lam_new[r] : lam[r];
+#pragma unroll
+        for (int j = 0; j < NB1; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lx[j][r] = has ? 0.0f : lx[j][r];
+        const int nsrc = a.item_prev[r_];
+        const int src2 = has ? nsrc : src;
+        load_source(src2, has);
+        src_i = has ? (src2 >= 0 ? a.t_of_row[src2 >= 0 ? src2 : 0] : -1) : src_i;
+        src = src2;
+      }
+      --i;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float* dst = (valid && uo[r] < H) ? a.g_hstart + (size_t)b * H + uo[r] : trash;
+    *dst = lam[r];
+  }
+}
+
+}  // namespace njode
