@@ -201,6 +201,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       FS::ode + FS::enc,
       FRAG2_OFF,
       ACT_FLOATS,
+      HAS_Q4 ? Q4_ACT_FLOATS : 0,
       HAS_MFMA_SWEEP ? 1 : 0,
       HAS_SPLIT ? 1 : 0,
       HAS_MFMA ? 1 : 0};

@@ -36,6 +36,7 @@ struct CfgOps {
   int frag_enc_off, frag_dec_off;  // offsets of the encoder / readout fragments in it
   int frag2_off;                   // ... of the scaled ODE table (njode_ode2.h)
   int act_floats;                  // stored ODE activations per chain and Euler step (0: none)
+  int lock_act_floats;             // lockstep plan (masked shapes): ... per tile of 16 paths and step
   int lock_sweep_mfma;  // the lockstep backward has a matrix-core adjoint sweep
   int ode_split;        // ODE_MFMA runs the mixed ODE kernels (njode_mfma_split.h)
   int seg_mfma;         // the segment plan has matrix-core kernels for this shape

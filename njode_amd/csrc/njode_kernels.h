@@ -107,6 +107,9 @@ struct KArgs {
   float* g_ybj;
   float* g_hnew;
   float* g_hstart;
+  // ... (masked models, njode_mfma_lock4.h) hidden activations of the ODE network at every step:
+  // [K][tiles of 16 paths][4 waves][2 layers x 4 registers][64 lanes]
+  float* lact;
   float* loss_terms;
   float* slab;
   float* trash;  // [64 * max(H, D)] scratch target for the stores of inactive lanes

@@ -47,8 +47,19 @@ template <class C> struct OdeQS {
 
 constexpr int q4_img_rows(int q) { return (4 * q + 15) / 16 * 16; }
 
-// this wave's forward fragments of one network
-template <class S> struct Q4Fwd {
+// Stored hidden activations of the ODE network (the forward stores what the adjoint sweep would
+// otherwise recompute with 35 more MFMAs, a fragment set that no longer fits the registers and
+// one more exchange per step): per Euler step and tile, wave w's own 2 x 4 registers, each
+// register one coalesced 256-B line.  Values are those the next layer consumed (dropout applied).
+constexpr int Q4_ACT_FLOATS = 4 * 8 * 64;
+NJ_DEV float* q4_act_ptr(float* lact, int k, int n_tiles, int tile, int w, int lane) {
+  return lact + (((size_t)k * n_tiles + tile) * 4 + w) * 8 * 64 + lane;
+}
+
+// This wave's fragments of one network, in registers (the networks every step / every jump
+// twice needs: ODE, readout) or in a wave-private LDS region (the encoder: once per jump).
+// Forward: W1, W2 tile w, W3 tile w.
+template <class S> struct Q4FwdReg {
   float A1[S::Q0], A2[S::Q1], A3[S::Q1];
   NJ_DEV void load(const float* frag, int w, int lane) {
     static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
@@ -60,10 +71,36 @@ template <class S> struct Q4Fwd {
 #pragma unroll
     for (int q = 0; q < S::Q1; ++q) A3[q] = frag[(S::F3 + wo * S::Q1 + q) * 64 + lane];
   }
+  NJ_DEV void begin() {}
+  NJ_DEV float a1(int q) const { return A1[q]; }
+  NJ_DEV float a2(int q) const { return A2[q]; }
+  NJ_DEV float a3(int q) const { return A3[q]; }
 };
-// ... and those of the adjoint sweep: hidden recompute + the three transposed products; the
-// input-gradient tiles w, w + 4, ... (NB1 of them)
-template <class S, int NB1> struct Q4Adj {
+template <class S> struct Q4FwdLds {
+  static constexpr int NVEC = S::Q0 + 2 * S::Q1;
+  lfp base, cur;
+  NJ_DEV void load(lfp region, const float* frag, int w, int lane) {   // region: NVEC * 64 floats
+    static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
+    base = region + lane;
+    cur = base;
+    for (int q = 0; q < S::Q0; ++q) base[q * 64] = frag[(S::F1 + w * S::Q0 + q) * 64 + lane];
+    for (int q = 0; q < S::Q1; ++q) base[(S::Q0 + q) * 64] = frag[(S::F2 + w * S::Q1 + q) * 64 + lane];
+    const int wo = w < S::MTO ? w : 0;
+    for (int q = 0; q < S::Q1; ++q)
+      base[(S::Q0 + S::Q1 + q) * 64] = frag[(S::F3 + wo * S::Q1 + q) * 64 + lane];
+  }
+  NJ_DEV void begin() {   // laundered per evaluation: the reads are not hoisted into registers
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lfp)(unsigned long long)v;
+  }
+  NJ_DEV float a1(int q) const { return cur[q * 64]; }
+  NJ_DEV float a2(int q) const { return cur[(S::Q0 + q) * 64]; }
+  NJ_DEV float a3(int q) const { return cur[(S::Q0 + S::Q1 + q) * 64]; }
+};
+// Adjoint sweep: hidden recompute + the three transposed products; input-gradient tiles w,
+// w + 4, ... (NB1 of them)
+template <class S, int NB1> struct Q4AdjReg {
   float A1[S::Q0], A2[S::Q1], B3[S::QO], B2[S::QW], B1[NB1][S::QW];
   NJ_DEV void load(const float* frag, int w, int lane) {
     static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
@@ -82,18 +119,71 @@ template <class S, int NB1> struct Q4Adj {
       for (int q = 0; q < S::QW; ++q) B1[j][q] = frag[(S::B1 + t * S::QW + q) * 64 + lane];
     }
   }
+  NJ_DEV void begin() {}
+  NJ_DEV float a1(int q) const { return A1[q]; }
+  NJ_DEV float a2(int q) const { return A2[q]; }
+  NJ_DEV float b3(int q) const { return B3[q]; }
+  NJ_DEV float b2(int q) const { return B2[q]; }
+  NJ_DEV float b1(int j, int q) const { return B1[j][q]; }
+};
+// the transposed products only (the sweep's Euler steps read the forward's activations)
+template <class S, int NB1> struct Q4AdjStep {
+  float B3[S::QO], B2[S::QW], B1[NB1][S::QW];
+  NJ_DEV void load(const float* frag, int w, int lane) {
+    static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
+#pragma unroll
+    for (int q = 0; q < S::QO; ++q) B3[q] = frag[(S::B3 + w * S::QO + q) * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < S::QW; ++q) B2[q] = frag[(S::B2 + w * S::QW + q) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+      const int t = w + 4 * j < S::MTI ? w + 4 * j : 0;
+#pragma unroll
+      for (int q = 0; q < S::QW; ++q) B1[j][q] = frag[(S::B1 + t * S::QW + q) * 64 + lane];
+    }
+  }
+  NJ_DEV float b3(int q) const { return B3[q]; }
+  NJ_DEV float b2(int q) const { return B2[q]; }
+  NJ_DEV float b1(int j, int q) const { return B1[j][q]; }
+};
+template <class S> struct Q4AdjLds {   // one input-gradient tile
+  static constexpr int O2 = S::Q0, O3 = O2 + S::Q1, O4 = O3 + S::QO, O5 = O4 + S::QW, NVEC = O5 + S::QW;
+  lfp base, cur;
+  NJ_DEV void load(lfp region, const float* frag, int w, int lane) {
+    static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
+    base = region + lane;
+    cur = base;
+    for (int q = 0; q < S::Q0; ++q) base[q * 64] = frag[(S::F1 + w * S::Q0 + q) * 64 + lane];
+    for (int q = 0; q < S::Q1; ++q) base[(O2 + q) * 64] = frag[(S::F2 + w * S::Q1 + q) * 64 + lane];
+    for (int q = 0; q < S::QO; ++q) base[(O3 + q) * 64] = frag[(S::B3 + w * S::QO + q) * 64 + lane];
+    for (int q = 0; q < S::QW; ++q) base[(O4 + q) * 64] = frag[(S::B2 + w * S::QW + q) * 64 + lane];
+    const int t = w < S::MTI ? w : 0;
+    for (int q = 0; q < S::QW; ++q) base[(O5 + q) * 64] = frag[(S::B1 + t * S::QW + q) * 64 + lane];
+  }
+  NJ_DEV void begin() {
+    unsigned v = (unsigned)(unsigned long long)base;
+    asm volatile("" : "+v"(v));
+    cur = (lfp)(unsigned long long)v;
+  }
+  NJ_DEV float a1(int q) const { return cur[q * 64]; }
+  NJ_DEV float a2(int q) const { return cur[(O2 + q) * 64]; }
+  NJ_DEV float b3(int q) const { return cur[(O3 + q) * 64]; }
+  NJ_DEV float b2(int q) const { return cur[(O4 + q) * 64]; }
+  NJ_DEV float b1(int, int q) const { return cur[(O5 + q) * 64]; }
 };
 
-// sum_q A[q] (x) b[q] on two accumulators (halves the dependent chain)
-template <int NQ> NJ_DEV f32x4 q4_dot(const float (&A)[NQ], const float (&b)[NQ]) {
+// sum_q A(q) (x) b[q] on two accumulators (halves the dependent chain)
+template <int NQ, class FA> NJ_DEV f32x4 q4_dot(FA fa, const float (&b)[NQ]) {
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < NQ; q += 2) {
-    s0 = mfma4(A[q], b[q], s0);
-    if (q + 1 < NQ) s1 = mfma4(A[q + 1], b[q + 1], s1);
+    s0 = mfma4(fa(q), b[q], s0);
+    if (q + 1 < NQ) s1 = mfma4(fa(q + 1), b[q + 1], s1);
   }
   return s0 + s1;
 }
+// the gathers of a layer input are issued as one batch, before the products that consume them
+NJ_DEV void q4_gathered() { __builtin_amdgcn_sched_barrier(0); }
 
 // own registers <-> image rows.  q4_put: all four rows (images of >= 64 rows, invalid units carry
 // zeros); q4_put_n: units < N only, at row offset row0
@@ -212,22 +302,48 @@ NJ_DEV void q4_ode_keep(const KArgs& a, unsigned long long gid, int k, int g, in
 }
 
 // forward of one network: b0 (all units) -> this wave's output tile.  Two exchanges.
-template <class S, int ACT, bool DROP>
-NJ_DEV f32x4 q4_net_fwd(const Q4Fwd<S>& F, lfp XA, lfp XB, const float (&b0)[S::Q0], uint32_t k1, uint32_t k2,
+template <class S, int ACT, bool DROP, class FP>
+NJ_DEV f32x4 q4_net_fwd(FP& F, lfp XA, lfp XB, const float (&b0)[S::Q0], uint32_t k1, uint32_t k2,
                         float inv_keep, int g, int c, int w) {
-  f32x4 acc = q4_dot<S::Q0>(F.A1, b0);
+  F.begin();
+  f32x4 acc = q4_dot<S::Q0>([&](int q) { return F.a1(q); }, b0);
   float al[4], av[S::Q1];
   q4_hidden<S::W, ACT, DROP>(acc, al, k1, inv_keep, g, w);
   q4_put(XA, al, g, c, w);
   block_lds_barrier();
   split_get<S::Q1>(XA, av, g, c);
-  acc = q4_dot<S::Q1>(F.A2, av);
+  q4_gathered();
+  acc = q4_dot<S::Q1>([&](int q) { return F.a2(q); }, av);
   q4_hidden<S::W, ACT, DROP>(acc, al, k2, inv_keep, g, w);
   q4_put(XB, al, g, c, w);
   block_lds_barrier();
   split_get<S::Q1>(XB, av, g, c);
+  q4_gathered();
   f32x4 out = {0.f, 0.f, 0.f, 0.f};
-  if (w < S::MTO) out = q4_dot<S::Q1>(F.A3, av);
+  if (w < S::MTO) out = q4_dot<S::Q1>([&](int q) { return F.a3(q); }, av);
+  return out;
+}
+
+// ... the same, handing back the own tiles of the two hidden activations
+template <class S, int ACT, bool DROP, class FP>
+NJ_DEV f32x4 q4_net_fwd_acts(FP& F, lfp XA, lfp XB, const float (&b0)[S::Q0], uint32_t k1, uint32_t k2,
+                             float inv_keep, int g, int c, int w, float (&a1l)[4], float (&a2l)[4]) {
+  F.begin();
+  f32x4 acc = q4_dot<S::Q0>([&](int q) { return F.a1(q); }, b0);
+  float av[S::Q1];
+  q4_hidden<S::W, ACT, DROP>(acc, a1l, k1, inv_keep, g, w);
+  q4_put(XA, a1l, g, c, w);
+  block_lds_barrier();
+  split_get<S::Q1>(XA, av, g, c);
+  q4_gathered();
+  acc = q4_dot<S::Q1>([&](int q) { return F.a2(q); }, av);
+  q4_hidden<S::W, ACT, DROP>(acc, a2l, k2, inv_keep, g, w);
+  q4_put(XB, a2l, g, c, w);
+  block_lds_barrier();
+  split_get<S::Q1>(XB, av, g, c);
+  q4_gathered();
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  if (w < S::MTO) out = q4_dot<S::Q1>([&](int q) { return F.a3(q); }, av);
   return out;
 }
 
@@ -246,13 +362,29 @@ NJ_DEV void q4_path_sums(lfp LR, float& sa, float& sb, int g, int c, int w) {
   sb = (LR[1 * 16 + c] + LR[3 * 16 + c]) + (LR[5 * 16 + c] + LR[7 * 16 + c]);
 }
 
+// maintainer aid (-DNJ_Q4_STAMP): phase timestamps of one Euler step, printed per wave
+#ifdef NJ_Q4_STAMP
+#define Q4_STAMP_DECL unsigned long long q4_ts[12]; int q4_nts = 0; (void)q4_ts; (void)q4_nts
+#define Q4_STAMP() do { if (q4_on && q4_nts < 12) q4_ts[q4_nts++] = __builtin_readcyclecounter(); } while (0)
+#define Q4_STAMP_PRINT(name) do { if (q4_on && lane == 0) { \
+    printf("%s w%d:", name, w); for (int i_ = 1; i_ < q4_nts; ++i_) printf(" %llu", q4_ts[i_] - q4_ts[i_ - 1]); \
+    printf(" | total %llu\n", q4_ts[q4_nts - 1] - q4_ts[0]); } q4_nts = 0; } while (0)
+#else
+#define Q4_STAMP_DECL
+#define Q4_STAMP()
+#define Q4_STAMP_PRINT(name)
+#endif
+
 template <class C> struct Q4Lds {
   using ES = typename EncS<C>::type;
   static constexpr int INR = q4_img_rows(MF<C>::Q0) > q4_img_rows(ES::Q0) ? q4_img_rows(MF<C>::Q0)
                                                                            : q4_img_rows(ES::Q0);
   static constexpr int IN_FL = INR * IMG_STRIDE;
-  // XA, XB, XD, HN (64 rows), IN, EI, LX (INR rows), LR
-  static constexpr int FLOATS = 4 * XFLOATS + 3 * IN_FL + 8 * 16;
+  // XA, XB, XD, HN (64 rows), IN, EI, LX (INR rows), LR; then the encoder fragments of the 4 waves
+  static constexpr int IMAGES = 4 * XFLOATS + 3 * IN_FL + 8 * 16;
+  static constexpr int FWD_FLOATS = IMAGES + 4 * Q4FwdLds<ES>::NVEC * 64;
+  static constexpr int ADJ_FLOATS = IMAGES + 4 * Q4AdjLds<ES>::NVEC * 64;
+  static_assert(ADJ_FLOATS * 4 <= 160 * 1024, "LDS budget");
 };
 
 // =====================================================================================
@@ -266,17 +398,17 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   using DS = typename DecS<C>::type;
   using L = Q4Lds<C>;
   constexpr int D = C::D, H = C::H, DO = C::DO;
-  __shared__ __attribute__((aligned(16))) float lds_raw[L::FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_raw[L::FWD_FLOATS];
   lfp XA = (lfp)lds_raw, XB = XA + XFLOATS, HN = XB + 2 * XFLOATS, IN = HN + XFLOATS, EI = IN + L::IN_FL,
       LR = EI + 2 * L::IN_FL;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < L::FLOATS; i += 256) lds_raw[i] = 0.0f;
-  Q4Fwd<OS> Fo;
-  Q4Fwd<ES> Fe;
-  Q4Fwd<DS> Fd;
+  for (int i = threadIdx.x; i < L::IMAGES; i += 256) lds_raw[i] = 0.0f;
+  Q4FwdReg<OS> Fo;
+  Q4FwdLds<ES> Fe;
+  Q4FwdReg<DS> Fd;
   Fo.load(a.frag, w, lane);
-  Fe.load(a.frag_enc, w, lane);
+  Fe.load((lfp)lds_raw + L::IMAGES + w * Q4FwdLds<ES>::NVEC * 64, a.frag_enc, w, lane);
   Fd.load(a.frag_dec, w, lane);
   __syncthreads();
 
@@ -297,6 +429,7 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   auto readout = [&](lfp TH, const float (&hq)[4], uint32_t tkey, uint32_t net, float (&y)[4]) {
     float b0d[DS::Q0];
     q4_input<H, DS::Q0>(TH, b0d, g, c);
+    q4_gathered();
     uint32_t k1, k2;
     q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
     const f32x4 out = q4_net_fwd<DS, C::ACT, DROP>(Fd, XA, XB, b0d, k1, k2, a.dc.inv_keep, g, c, w);
@@ -311,6 +444,7 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   auto encode = [&](const float (&xin)[4], uint32_t tkey, float (&hq)[4]) {
     float b0e[ES::Q0];
     q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
+    q4_gathered();
     uint32_t k1, k2;
     q4_row_keep<DROP>(a, gid, tkey, NET_ENC, g, w, k1, k2);
     const f32x4 out = q4_net_fwd<ES, C::ACT, DROP>(Fe, XA, XB, b0e, k1, k2, a.dc.inv_keep, g, c, w);
@@ -340,15 +474,35 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   q4_put_n<H>(IN, 0, th, g, c, w);
   block_lds_barrier();
 
+  // checkpoint / activation store addresses advance by a constant per step (inactive lanes and
+  // units keep writing to `trash`)
+  float* lt_p[4];
+  long long lt_step[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = SAVE && valid && uo[r] < H;
+    lt_p[r] = ok ? a.ltraj + (size_t)b * H + uo[r] : trash;
+    lt_step[r] = ok ? (long long)a.B * H : 0;
+  }
+  const int n_tiles = (int)gridDim.x;
+  float* la_p = SAVE ? q4_act_ptr(a.lact, 0, n_tiles, blockIdx.x, w, lane) : trash;
+  const long long la_step = SAVE ? (long long)n_tiles * Q4_ACT_FLOATS : 0;
+  const int la_r = SAVE ? 64 : 0;
+
   float tau = 0.0f, loss_acc = 0.0f;
   int cur = a.first_j[b];
   int next_i = a.n_obs > 0 ? a.t_of_row[a.row_by_path[cur >= 0 ? cur : 0]] : 0;
   next_i = cur >= 0 ? next_i : 0x7fffffff;
   int src = -1;
 
+  // the schedule's scalars are loaded one step / one jump ahead (their latency would otherwise
+  // sit on the critical path of every step)
   int i = 0;
+  int kj = a.n_times > 0 ? kjump[0] : -1;
+  float dt_n = a.K > 0 ? sdt[0] : 0.0f, t_n = a.K > 0 ? stt[0] : 0.0f;
   for (int k = 0;; ++k) {
-    while (i < a.n_times && kjump[i] == k) {
+    while (i < a.n_times && kj == k) {
+      kj = i + 1 < a.n_times ? kjump[i + 1] : -1;
       const bool has = valid && next_i == i;
       if (__any(has)) {   // the same decision in all four waves
         const int r_ = has ? a.row_by_path[cur >= 0 ? cur : 0] : 0;
@@ -437,27 +591,47 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
     }
     if (SAVE) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* dst = (valid && uo[r] < H) ? a.ltraj + ((size_t)k * a.B + b) * H + uo[r] : trash;
-        *dst = h[r];
-      }
+      for (int r = 0; r < 4; ++r) *lt_p[r] = h[r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lt_p[r] += lt_step[r];
       if (valid && w == 0 && g == 0 && k < a.K) a.src_row[(size_t)k * a.B + b] = src;
     }
     if (k >= a.K) break;
     {
-      const float dt = sdt[k], t = stt[k];
+      const float dt = dt_n, t = t_n;
+      if (k + 1 < a.K) {
+        dt_n = sdt[k + 1];
+        t_n = stt[k + 1];
+      }
+#ifdef NJ_Q4_STAMP
+      const bool q4_on = blockIdx.x == 0 && (k == a.K / 2 || k == a.K / 2 + 1);
+#endif
+      Q4_STAMP_DECL;
+      Q4_STAMP();
       float b0[M::Q0];
       q4_in0<C>(IN, b0, tau, t - tau, g, c);
+      q4_gathered();
       uint32_t k1, k2;
       q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
-      const f32x4 out = q4_net_fwd<OS, C::ACT, DROP>(Fo, XA, XB, b0, k1, k2, a.dc.inv_keep, g, c, w);
+      float a1l[4], a2l[4];
+      const f32x4 out = q4_net_fwd_acts<OS, C::ACT, DROP>(Fo, XA, XB, b0, k1, k2, a.dc.inv_keep, g, c, w,
+                                                          a1l, a2l);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {   // (an evaluation forward writes them to `trash`)
+        la_p[r * la_r] = a1l[r];
+        la_p[(4 + r) * la_r] = a2l[r];
+      }
+      la_p += la_step;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         h[r] = uo[r] < H ? fmaf(dt, out[r], h[r]) : 0.0f;
         th[r] = tanh_f(h[r]);
       }
       q4_put_n<H>(IN, 0, th, g, c, w);
+      Q4_STAMP();
       block_lds_barrier();
+      Q4_STAMP();
+      Q4_STAMP_PRINT("fwd");
     }
   }
 #pragma unroll
@@ -481,17 +655,17 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   constexpr int D = C::D, H = C::H, DO = C::DO;
   constexpr int NB1 = (M::MTB1 + 3) / 4;   // in0 gradient tiles per wave
   static_assert((D + 15) / 16 <= 4 && DS::MTI <= 4, "one input-gradient tile per wave for the row networks");
-  __shared__ __attribute__((aligned(16))) float lds_raw[L::FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_raw[L::ADJ_FLOATS];
   lfp XA = (lfp)lds_raw, XB = XA + XFLOATS, XD = XB + XFLOATS, HN = XD + XFLOATS, IN = HN + XFLOATS,
       EI = IN + L::IN_FL, LX = EI + L::IN_FL, LR = LX + L::IN_FL;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < L::FLOATS; i += 256) lds_raw[i] = 0.0f;
-  Q4Adj<OS, NB1> Fo;
-  Q4Adj<ES, 1> Fe;
-  Q4Adj<DS, 1> Fd;
+  for (int i = threadIdx.x; i < L::IMAGES; i += 256) lds_raw[i] = 0.0f;
+  Q4AdjStep<OS, NB1> Fo;
+  Q4AdjLds<ES> Fe;
+  Q4AdjReg<DS, 1> Fd;
   Fo.load(a.frag, w, lane);
-  Fe.load(a.frag_enc, w, lane);
+  Fe.load((lfp)lds_raw + L::IMAGES + w * Q4AdjLds<ES>::NVEC * 64, a.frag_enc, w, lane);
   Fd.load(a.frag_dec, w, lane);
   __syncthreads();
 
@@ -539,28 +713,33 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
     q4_put(XD, dy, g, c, w);
     block_lds_barrier();
     q4_input<H, DS::Q0>(HN, b0d, g, c);
+    q4_gathered();
     uint32_t k1, k2;
     q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
-    f32x4 acc = q4_dot<DS::Q0>(Fd.A1, b0d);
+    Fd.begin();
+    f32x4 acc = q4_dot<DS::Q0>([&](int q) { return Fd.a1(q); }, b0d);
     q4_hidden<DS::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
     q4_put(XA, a1l, g, c, w);
     block_lds_barrier();
     split_get<DS::Q1>(XA, av, g, c);
-    acc = q4_dot<DS::Q1>(Fd.A2, av);
-    q4_hidden<DS::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
     split_get<DS::QO>(XD, dq, g, c);
-    acc = q4_dot<DS::QO>(Fd.B3, dq);
+    q4_gathered();
+    acc = q4_dot<DS::Q1>([&](int q) { return Fd.a2(q); }, av);
+    q4_hidden<DS::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
+    acc = q4_dot<DS::QO>([&](int q) { return Fd.b3(q); }, dq);
     q4_delta<DS::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
     q4_put(XB, dl, g, c, w);
     block_lds_barrier();
     split_get<DS::QW>(XB, dv, g, c);
-    acc = q4_dot<DS::QW>(Fd.B2, dv);
+    q4_gathered();
+    acc = q4_dot<DS::QW>([&](int q) { return Fd.b2(q); }, dv);
     q4_delta<DS::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
     q4_put(XA, dl, g, c, w);
     block_lds_barrier();
     split_get<DS::QW>(XA, dv, g, c);
+    q4_gathered();
     f32x4 din = {0.f, 0.f, 0.f, 0.f};
-    if (w < DS::MTI) din = q4_dot<DS::QW>(Fd.B1[0], dv);
+    if (w < DS::MTI) din = q4_dot<DS::QW>([&](int q) { return Fd.b1(0, q); }, dv);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = din[r] * (1.0f - thq[r] * thq[r]);
@@ -569,62 +748,92 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
     }
   };
 
-  float h_n[4];   // state before step k, loaded one step ahead
-  auto fetch_h = [&](int k, float (&hh)[4]) {
+  // state before step k and the forward's hidden activations, loaded one step ahead (raw: the
+  // selects happen at the use, so that nothing waits for the loads where they are issued)
+  const int n_tiles = (int)gridDim.x;
+  float h_n[4], a1_n[4], a2_n[4];
+  const float* lt_p[4];
+  float* lm_p[4];
+  long long lt_step[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = valid && uo[r] < H;
+    const size_t off = (size_t)b * H + (uo[r] < H ? uo[r] : 0);
+    lt_p[r] = a.ltraj + ((size_t)(a.K > 0 ? a.K - 1 : 0) * a.B) * H + off;
+    lm_p[r] = ok ? a.lam_traj + ((size_t)(a.K > 0 ? a.K - 1 : 0) * a.B) * H + off : trash;
+    lt_step[r] = ok ? (long long)a.B * H : 0;
+  }
+  const long long lt_back = (long long)a.B * H;
+  const float* la_p = q4_act_ptr(a.lact, a.K > 0 ? a.K - 1 : 0, n_tiles, blockIdx.x, w, lane);
+  const long long la_step = (long long)n_tiles * Q4_ACT_FLOATS;
+  auto fetch = [&]() {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v = a.ltraj[((size_t)k * a.B + b) * H + (uo[r] < H ? uo[r] : 0)];
-      hh[r] = uo[r] < H ? v : 0.0f;
+      h_n[r] = *lt_p[r];
+      a1_n[r] = la_p[r * 64];
+      a2_n[r] = la_p[(4 + r) * 64];
+      lt_p[r] -= lt_back;
     }
+    la_p -= la_step;
   };
-  if (a.K > 0) fetch_h(a.K - 1, h_n);
+  if (a.K > 0) fetch();
 
   int i = a.n_times - 1;
+  int kj = i >= 0 ? kjump[i] : -1;   // the schedule's scalars: one step / one jump ahead
+  float dt_n = a.K > 0 ? sdt[a.K - 1] : 0.0f;
   for (int k = a.K; k >= 0; --k) {
     if (k < a.K) {
-      // ---- reverse Euler step k
-      float th[4], d3[4], b0[M::Q0], a1l[4], a2l[4], dl[4], av[M::Q1], dq[M::QH], dv[M::QW];
-      const float dt = sdt[k], t = stt[k];
+      // ---- reverse Euler step k (hidden activations from the forward: no recompute)
+      float th[4], d3[4], a1l[4], a2l[4], dl[4], dq[M::QH], dv[M::QW];
+      const float dt = dt_n;
+      if (k > 0) dt_n = sdt[k - 1];
+#ifdef NJ_Q4_STAMP
+      const bool q4_on = blockIdx.x == 0 && (k == a.K / 2 || k == a.K / 2 + 1);
+#endif
+      Q4_STAMP_DECL;
+      Q4_STAMP();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         th[r] = uo[r] < H ? tanh_f(h_n[r]) : 0.0f;
+        a1l[r] = a1_n[r];
+        a2l[r] = a2_n[r];
         d3[r] = dt * lam[r];
       }
-      if (k > 0) fetch_h(k - 1, h_n);
-      q4_put_n<H>(IN, 0, th, g, c, w);
+      if (k > 0) fetch();
       q4_put(XD, d3, g, c, w);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float* dst = (valid && uo[r] < H) ? a.lam_traj + ((size_t)k * a.B + b) * H + uo[r] : trash;
-        *dst = lam[r];
+        *lm_p[r] = lam[r];
+        lm_p[r] -= lt_step[r];
       }
-      block_lds_barrier();                                   // (1) in0 and delta3 of all tiles
-      q4_in0<C>(IN, b0, tau, t - tau, g, c);
+      Q4_STAMP();
+      block_lds_barrier();                                   // (1) delta3 of all tiles
+      Q4_STAMP();
       uint32_t k1, k2;
       q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
-      f32x4 acc = q4_dot<M::Q0>(Fo.A1, b0);
-      q4_hidden<C::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
-      q4_put(XA, a1l, g, c, w);
-      block_lds_barrier();                                   // (2) a1
-      split_get<M::Q1>(XA, av, g, c);
-      acc = q4_dot<M::Q1>(Fo.A2, av);
-      q4_hidden<C::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
       split_get<M::QH>(XD, dq, g, c);
-      acc = q4_dot<M::QH>(Fo.B3, dq);
+      q4_gathered();
+      f32x4 acc = q4_dot<M::QH>([&](int q) { return Fo.b3(q); }, dq);
       q4_delta<C::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
       q4_put(XB, dl, g, c, w);
-      block_lds_barrier();                                   // (3) delta2
+      Q4_STAMP();
+      block_lds_barrier();                                   // (2) delta2
+      Q4_STAMP();
       split_get<M::QW>(XB, dv, g, c);
-      acc = q4_dot<M::QW>(Fo.B2, dv);
+      q4_gathered();
+      acc = q4_dot<M::QW>([&](int q) { return Fo.b2(q); }, dv);
       q4_delta<C::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
       q4_put(XA, dl, g, c, w);
-      block_lds_barrier();                                   // (4) delta1
+      Q4_STAMP();
+      block_lds_barrier();                                   // (3) delta1
+      Q4_STAMP();
       split_get<M::QW>(XA, dv, g, c);
+      q4_gathered();
       // in0 units: [h (H), x (D), ...]; both are tanh'd inputs whose values sit in the image
 #pragma unroll
       for (int j = 0; j < NB1; ++j) {
         if (w + 4 * j < M::MTB1) {
-          const f32x4 din = q4_dot<M::QW>(Fo.B1[j], dv);
+          const f32x4 din = q4_dot<M::QW>([&](int q) { return Fo.b1(j, q); }, dv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int u = 16 * (w + 4 * j) + 4 * r + g;
@@ -637,9 +846,12 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
           }
         }
       }
+      Q4_STAMP();
+      Q4_STAMP_PRINT("bwd");
     }
     // ---- reverse the jump applied right before step k
-    while (i >= 0 && kjump[i] == k) {
+    while (i >= 0 && kj == k) {
+      kj = i > 0 ? kjump[i - 1] : -1;
       const bool has = valid && src >= 0 && src_i == i;
       if (__any(has)) {
         const int r_ = has ? src : 0;
@@ -733,28 +945,33 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
           q4_put(XD, lam_hn, g, c, w);
           block_lds_barrier();
           q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
+          q4_gathered();
           uint32_t k1, k2;
           q4_row_keep<DROP>(a, gid, (uint32_t)k, NET_ENC, g, w, k1, k2);
-          f32x4 acc = q4_dot<ES::Q0>(Fe.A1, b0e);
+          Fe.begin();
+          f32x4 acc = q4_dot<ES::Q0>([&](int q) { return Fe.a1(q); }, b0e);
           q4_hidden<ES::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
           q4_put(XA, a1l, g, c, w);
           block_lds_barrier();
           split_get<ES::Q1>(XA, av, g, c);
-          acc = q4_dot<ES::Q1>(Fe.A2, av);
-          q4_hidden<ES::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
           split_get<ES::QO>(XD, dq, g, c);
-          acc = q4_dot<ES::QO>(Fe.B3, dq);
+          q4_gathered();
+          acc = q4_dot<ES::Q1>([&](int q) { return Fe.a2(q); }, av);
+          q4_hidden<ES::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
+          acc = q4_dot<ES::QO>([&](int q) { return Fe.b3(q); }, dq);
           q4_delta<ES::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
           q4_put(XB, dl, g, c, w);
           block_lds_barrier();
           split_get<ES::QW>(XB, dv, g, c);
-          acc = q4_dot<ES::QW>(Fe.B2, dv);
+          q4_gathered();
+          acc = q4_dot<ES::QW>([&](int q) { return Fe.b2(q); }, dv);
           q4_delta<ES::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
           q4_put(XA, dl, g, c, w);
           block_lds_barrier();
           split_get<ES::QW>(XA, dv, g, c);
+          q4_gathered();
           f32x4 din = {0.f, 0.f, 0.f, 0.f};
-          if (w < (D + 15) / 16) din = q4_dot<ES::QW>(Fe.B1[0], dv);
+          if (w < (D + 15) / 16) din = q4_dot<ES::QW>([&](int q) { return Fe.b1(0, q); }, dv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = din[r] * (1.0f - txin[r] * txin[r]);
