@@ -260,7 +260,7 @@ template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) 
 }
 template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_Q4) {
-    if (!a.want_path && lock4_on()) {
+    if (!a.want_path && lock4_on() && (!a.save_traj || a.lact)) {
       k_paths_fwd_q4<CC, DROP><<<cdiv(a.B, 16), 256, 0, st>>>(a);
       return;
     }
@@ -300,7 +300,7 @@ template <class CC, bool DROP> static void lock_bwd_mfma(const KArgs& a, hipStre
       ProfScope ps("k_paths_bwd_adj_mfma", st);
       bool q4 = false;
       if constexpr (HAS_Q4) {
-        if (lock4_on()) {
+        if (lock4_on() && a.lact) {   // (lact: the saving forward was k_paths_fwd_q4)
           k_paths_bwd_adj_q4<CC, DROP><<<cdiv(a.B, 16), 256, 0, st>>>(a);
           q4 = true;
         }

@@ -262,7 +262,10 @@ NJ_DEV void q4_hidden(const f32x4& acc, float (&al)[4], uint32_t keep4, float in
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float v = act_f<ACT>(acc[r]);
-    if constexpr (DROP) v = ((keep4 >> r) & 1) ? v * inv_keep : 0.0f;
+    // a dropped unit is -0.0f: the same zero to every product, and a mark the adjoint sweep can
+    // read back from the stored activation (a kept unit can be exactly +0: zero biases, zero
+    // start values; it is never -0, the accumulators start from +0)
+    if constexpr (DROP) v = ((keep4 >> r) & 1) ? v * inv_keep : -0.0f;
     al[r] = v;
   }
   if (w == W / 16) al[(W % 16) / 4] = g == W % 4 ? 1.0f : al[(W % 16) / 4];
@@ -276,6 +279,20 @@ NJ_DEV void q4_delta(const f32x4& acc, const float (&al)[4], float (&dl)[4], uin
     if constexpr (DROP) d = ((keep4 >> r) & 1) ? acc[r] * inv_keep * dact_f<ACT>(al[r] * keepf) : 0.0f;
     else d = acc[r] * dact_f<ACT>(al[r]);
     dl[r] = (16 * w + 4 * r + g) < W ? d : 0.0f;   // bias / padding units carry no delta
+  }
+}
+
+// ... from an activation the forward stored: a dropped unit is -0.0f there (q4_hidden)
+template <int W, int ACT, bool DROP>
+NJ_DEV void q4_delta_stored(const f32x4& acc, const float (&al)[4], float (&dl)[4], float inv_keep,
+                            float keepf, int g, int w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float d;
+    if constexpr (DROP)
+      d = __float_as_uint(al[r]) != 0x80000000u ? acc[r] * inv_keep * dact_f<ACT>(al[r] * keepf) : 0.0f;
+    else d = acc[r] * dact_f<ACT>(al[r]);
+    dl[r] = (16 * w + 4 * r + g) < W ? d : 0.0f;
   }
 }
 
@@ -294,10 +311,16 @@ NJ_DEV void q4_ode_keep(const KArgs& a, unsigned long long gid, int k, int g, in
   if constexpr (DROP) {
     uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1), (uint32_t)k,
                              NET_ODE);
-    const uint32_t f1 = keep_bits<MF<C>::Q1>(st, a.dc.thr16);
-    const uint32_t f2 = keep_bits<MF<C>::Q1>(st, a.dc.thr16);
-    k1 = (f1 >> (4 * w)) & 15u;
-    k2 = (f2 >> (4 * w)) & 15u;
+    // unit 4q + g is bit q of the lane group's stream, NWD words per layer (njode_mfma.h): this
+    // wave's bits 4w .. 4w+3 are words 2w, 2w+1 of each layer -- skip the others
+    constexpr int NWD = (MF<C>::Q1 + 1) / 2;
+    auto skip = [&](int n) {
+      for (int i_ = 0; i_ < n; ++i_) { st ^= st << 13; st ^= st >> 17; st ^= st << 5; }
+    };
+    skip(2 * w);
+    k1 = keep_bits<4>(st, a.dc.thr16);
+    skip(NWD - 2);
+    k2 = keep_bits<4>(st, a.dc.thr16);
   }
 }
 
@@ -367,8 +390,9 @@ NJ_DEV void q4_path_sums(lfp LR, float& sa, float& sb, int g, int c, int w) {
 #define Q4_STAMP_DECL unsigned long long q4_ts[12]; int q4_nts = 0; (void)q4_ts; (void)q4_nts
 #define Q4_STAMP() do { if (q4_on && q4_nts < 12) q4_ts[q4_nts++] = __builtin_readcyclecounter(); } while (0)
 #define Q4_STAMP_PRINT(name) do { if (q4_on && lane == 0) { \
-    printf("%s w%d:", name, w); for (int i_ = 1; i_ < q4_nts; ++i_) printf(" %llu", q4_ts[i_] - q4_ts[i_ - 1]); \
-    printf(" | total %llu\n", q4_ts[q4_nts - 1] - q4_ts[0]); } q4_nts = 0; } while (0)
+    unsigned long long d_[10]; for (int i_ = 0; i_ < 10; ++i_) d_[i_] = i_ + 1 < q4_nts ? q4_ts[i_ + 1] - q4_ts[i_] : 0; \
+    printf("%s w%d: %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu | total %llu\n", name, w, d_[0], d_[1], d_[2], d_[3], \
+           d_[4], d_[5], d_[6], d_[7], d_[8], d_[9], q4_ts[q4_nts - 1] - q4_ts[0]); } q4_nts = 0; } while (0)
 #else
 #define Q4_STAMP_DECL
 #define Q4_STAMP()
@@ -491,8 +515,13 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
 
   float tau = 0.0f, loss_acc = 0.0f;
   int cur = a.first_j[b];
-  int next_i = a.n_obs > 0 ? a.t_of_row[a.row_by_path[cur >= 0 ? cur : 0]] : 0;
+  // row and time index of this path's next observation; after a jump they are reloaded, and the
+  // loaded values are only looked at when the next jump time comes up (p_*: pending reload)
+  int r_cur = a.n_obs > 0 ? a.row_by_path[cur >= 0 ? cur : 0] : 0;
+  int next_i = a.n_obs > 0 ? a.t_of_row[r_cur] : 0;
   next_i = cur >= 0 ? next_i : 0x7fffffff;
+  bool p_on = false;
+  int p_row = 0, p_path = 0, p_time = 0;
   int src = -1;
 
   // the schedule's scalars are loaded one step / one jump ahead (their latency would otherwise
@@ -503,10 +532,27 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   for (int k = 0;; ++k) {
     while (i < a.n_times && kj == k) {
       kj = i + 1 < a.n_times ? kjump[i + 1] : -1;
+      {   // resolve the pending reload
+        const int nx = (cur < a.n_obs && p_path == b) ? p_time : 0x7fffffff;
+        next_i = p_on ? nx : next_i;
+        r_cur = p_on ? p_row : r_cur;
+        p_on = false;
+      }
       const bool has = valid && next_i == i;
       if (__any(has)) {   // the same decision in all four waves
-        const int r_ = has ? a.row_by_path[cur >= 0 ? cur : 0] : 0;
-        float ybj[4], yn[4], x[4], m[4], xin[4], txin[4], hn[4], thn[4];
+        const int r_ = has ? r_cur : 0;
+        float ybj[4], yn[4], x[4], m[4], xin[4], txin[4], hn[4], thn[4], xraw[4], mraw[4];
+        // the row's values are needed after the first readout: loaded beside it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = uo[r] < D ? uo[r] : 0;
+          xraw[r] = a.X[(size_t)r_ * D + u];
+          mraw[r] = C::MASKED ? a.M[(size_t)r_ * D + u] : 1.0f;
+        }
+        // ... and so is the path's next row (its time index is loaded at the commit below)
+        const int cn = cur + 1;
+        const int cc = cn < a.n_obs ? cn : 0;
+        const int n_row = a.row_by_path[cc], n_path = a.path_sorted[cc];
         if (SAVE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -517,12 +563,9 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
         readout(IN, h, (uint32_t)k, NET_DEC_BJ, ybj);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int u = uo[r] < D ? uo[r] : 0;
-          const float xv = a.X[(size_t)r_ * D + u];
-          x[r] = uo[r] < D ? xv : 0.0f;
+          x[r] = uo[r] < D ? xraw[r] : 0.0f;
           if constexpr (C::MASKED) {
-            const float mv = a.M[(size_t)r_ * D + u];
-            m[r] = uo[r] < D ? mv : 0.0f;
+            m[r] = uo[r] < D ? mraw[r] : 0.0f;
             xin[r] = x[r] * m[r] + (1.0f - m[r]) * ybj[r];
           } else {
             m[r] = uo[r] < D ? 1.0f : 0.0f;
@@ -580,12 +623,12 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
         const float tnew = tf[i];
         tau = has ? tnew : tau;
         src = has ? r_ : src;
-        const int cn = cur + 1;
-        const int cc = cn < a.n_obs ? cn : 0;
-        const int nt_ = a.t_of_row[a.row_by_path[cc]];
-        const int nexti2 = (cn < a.n_obs && a.path_sorted[cc] == b) ? nt_ : 0x7fffffff;
+        p_row = n_row;
+        p_path = n_path;
+        p_time = a.t_of_row[n_row];
+        p_on = has;
         cur = has ? cn : cur;
-        next_i = has ? nexti2 : next_i;
+        next_i = has ? 0x7fffffff : next_i;   // (until the reload is resolved)
       }
       ++i;
     }
@@ -604,7 +647,7 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
         t_n = stt[k + 1];
       }
 #ifdef NJ_Q4_STAMP
-      const bool q4_on = blockIdx.x == 0 && (k == a.K / 2 || k == a.K / 2 + 1);
+      const bool q4_on = blockIdx.x == 0 && k == a.K / 2;
 #endif
       Q4_STAMP_DECL;
       Q4_STAMP();
@@ -676,7 +719,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   float* const trash = a.trash + threadIdx.x;
   const int __attribute__((address_space(4)))* kjump =
       (const int __attribute__((address_space(4)))*)(unsigned long long)a.k_jump;
-  const cfp sdt = as_cfp(a.step_dt), stt = as_cfp(a.step_t);
+  const cfp sdt = as_cfp(a.step_dt);
   int uo[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) uo[r] = 16 * w + 4 * r + g;
@@ -687,22 +730,40 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   for (int j = 0; j < NB1; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) lx[j][r] = 0.0f;
-  int src = a.last_row[b];
-  int src_i = src >= 0 ? a.t_of_row[src] : -1;
-  float tau = 0.0f;
-  // last_X / tau of the segment that follows row `srow` (or the start value): image rows H + u
-  auto load_source = [&](int srow, bool on) {
-    const int sv = srow >= 0 ? srow : 0;
-    const float* xp = srow >= 0 ? (C::MASKED ? a.y_row + (size_t)sv * DO : a.X + (size_t)sv * D)
-                                : a.start_X + (size_t)b * D;
+  // The row this path reverses next (`src`), what the sweep needs of it (its time index, its
+  // predecessor row, h before the jump, X, M, y, y_bj: own units), loaded when `src` is assigned --
+  // under the lanes' exec mask, so nothing waits for these loads before the jump that uses them.
+  int src = a.last_row[b], src_i = -1, src_pp = -1;
+  float Rhp[4] = {0.f, 0.f, 0.f, 0.f}, Rx[4] = {0.f, 0.f, 0.f, 0.f}, Rm[4] = {0.f, 0.f, 0.f, 0.f},
+        Ry[4] = {0.f, 0.f, 0.f, 0.f}, Rybj[4] = {0.f, 0.f, 0.f, 0.f}, sx0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sx0[r] = a.start_X[(size_t)b * D + (uo[r] < D ? uo[r] : 0)];
+  auto load_rows = [&](int srow, bool on) {
+    if (on && srow >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uh = uo[r] < H ? uo[r] : 0, ud = uo[r] < D ? uo[r] : 0;
+        Rhp[r] = a.h_end[(size_t)srow * H + uh];
+        Rx[r] = a.X[(size_t)srow * D + ud];
+        if constexpr (C::MASKED) Rm[r] = a.M[(size_t)srow * D + ud];
+        Ry[r] = a.y_row[(size_t)srow * DO + ud];
+        Rybj[r] = a.ybj_row[(size_t)srow * DO + ud];
+      }
+      src_pp = a.item_prev[srow];
+      src_i = a.t_of_row[srow];
+    }
+    if (on && srow < 0) src_i = -1;
+  };
+  load_rows(src, true);
+  // last_X of the segment that follows row `src` (its prediction; the start value before the
+  // first row) -> image rows H + u; refreshed lazily inside the next Euler step
+  bool tx_dirty = true;
+  auto put_source = [&]() {
     float tx[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tx[r] = tanh_f(xp[uo[r] < D ? uo[r] : 0]);
-    q4_put_n_if<D>(IN, H, tx, on, g, c, w);
-    const float tsrc = a.n_obs > 0 ? a.time_f32[a.t_of_row[sv]] : 0.0f;
-    tau = on ? (srow >= 0 ? tsrc : 0.0f) : tau;
+    for (int r = 0; r < 4; ++r) tx[r] = tanh_f(src >= 0 ? (C::MASKED ? Ry[r] : Rx[r]) : sx0[r]);
+    q4_put_n<D>(IN, H, tx, g, c, w);
   };
-  load_source(src, true);
 
   // adjoint of y = readout(hq) w.r.t. hq: own tile of dh from the own tile of dy
   auto dec_adj = [&](const float (&hq)[4], const float (&dy)[4], uint32_t tkey, uint32_t net, float (&dh)[4]) {
@@ -751,7 +812,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   // state before step k and the forward's hidden activations, loaded one step ahead (raw: the
   // selects happen at the use, so that nothing waits for the loads where they are issued)
   const int n_tiles = (int)gridDim.x;
-  float h_n[4], a1_n[4], a2_n[4];
+  float h_cur[4] = {0.f, 0.f, 0.f, 0.f};
   const float* lt_p[4];
   float* lm_p[4];
   long long lt_step[4];
@@ -766,40 +827,54 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   const long long lt_back = (long long)a.B * H;
   const float* la_p = q4_act_ptr(a.lact, a.K > 0 ? a.K - 1 : 0, n_tiles, blockIdx.x, w, lane);
   const long long la_step = (long long)n_tiles * Q4_ACT_FLOATS;
-  auto fetch = [&]() {
+  // Two steps ahead (a step is shorter than a trip to HBM): step k consumes set k & 1 and
+  // refills it with the data of step k - 2; the set index is a compile-time constant of the two
+  // instances of the step body, so there are no register copies that would wait for the loads.
+  float hb[2][4], a1b[2][4], a2b[2][4];
+  auto fetch = [&](auto SET) {
+    constexpr int S_ = decltype(SET)::value;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      h_n[r] = *lt_p[r];
-      a1_n[r] = la_p[r * 64];
-      a2_n[r] = la_p[(4 + r) * 64];
+      hb[S_][r] = *lt_p[r];
+      a1b[S_][r] = la_p[r * 64];
+      a2b[S_][r] = la_p[(4 + r) * 64];
       lt_p[r] -= lt_back;
     }
     la_p -= la_step;
   };
-  if (a.K > 0) fetch();
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  if (a.K > 0) {   // step K - 1, then step K - 2
+    if ((a.K - 1) & 1) fetch(Set1{}); else fetch(Set0{});
+  }
+  if (a.K > 1) {
+    if ((a.K - 2) & 1) fetch(Set1{}); else fetch(Set0{});
+  }
 
   int i = a.n_times - 1;
   int kj = i >= 0 ? kjump[i] : -1;   // the schedule's scalars: one step / one jump ahead
   float dt_n = a.K > 0 ? sdt[a.K - 1] : 0.0f;
   for (int k = a.K; k >= 0; --k) {
-    if (k < a.K) {
-      // ---- reverse Euler step k (hidden activations from the forward: no recompute)
+    // ---- reverse Euler step k (hidden activations from the forward: no recompute)
+    auto euler_step = [&](auto SET) {
+      constexpr int S_ = decltype(SET)::value;
       float th[4], d3[4], a1l[4], a2l[4], dl[4], dq[M::QH], dv[M::QW];
       const float dt = dt_n;
       if (k > 0) dt_n = sdt[k - 1];
 #ifdef NJ_Q4_STAMP
-      const bool q4_on = blockIdx.x == 0 && (k == a.K / 2 || k == a.K / 2 + 1);
+      const bool q4_on = blockIdx.x == 0 && k == a.K / 2;
 #endif
       Q4_STAMP_DECL;
       Q4_STAMP();
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        th[r] = uo[r] < H ? tanh_f(h_n[r]) : 0.0f;
-        a1l[r] = a1_n[r];
-        a2l[r] = a2_n[r];
+        h_cur[r] = hb[S_][r];
+        th[r] = uo[r] < H ? tanh_f(hb[S_][r]) : 0.0f;
+        a1l[r] = a1b[S_][r];
+        a2l[r] = a2b[S_][r];
         d3[r] = dt * lam[r];
       }
-      if (k > 0) fetch();
+      if (k > 1) fetch(SET);
       q4_put(XD, d3, g, c, w);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -809,12 +884,24 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
       Q4_STAMP();
       block_lds_barrier();                                   // (1) delta3 of all tiles
       Q4_STAMP();
-      uint32_t k1, k2;
-      q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
       split_get<M::QH>(XD, dq, g, c);
       q4_gathered();
       f32x4 acc = q4_dot<M::QH>([&](int q) { return Fo.b3(q); }, dq);
-      q4_delta<C::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
+#ifdef NJ_Q4_CHECK
+      {
+        uint32_t c1, c2;
+        q4_ode_keep<C, DROP>(a, gid, k, g, w, c1, c2);
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * w + 4 * r + g;
+          if (DROP && valid && u < C::W) {
+            const bool k1b = (c1 >> r) & 1, k2b = (c2 >> r) & 1;
+            if (k1b != (__float_as_uint(a1l[r]) != 0x80000000u) || k2b != (__float_as_uint(a2l[r]) != 0x80000000u))
+              printf("mismatch k=%d b=%d u=%d keep=(%d,%d) a=(%g,%g)\n", k, b, u, (int)k1b, (int)k2b, a1l[r], a2l[r]);
+          }
+        }
+      }
+#endif
+      q4_delta_stored<C::W, C::ACT, DROP>(acc, a2l, dl, a.dc.inv_keep, a.keep, g, w);
       q4_put(XB, dl, g, c, w);
       Q4_STAMP();
       block_lds_barrier();                                   // (2) delta2
@@ -822,10 +909,14 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
       split_get<M::QW>(XB, dv, g, c);
       q4_gathered();
       acc = q4_dot<M::QW>([&](int q) { return Fo.b2(q); }, dv);
-      q4_delta<C::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
+      q4_delta_stored<C::W, C::ACT, DROP>(acc, a1l, dl, a.dc.inv_keep, a.keep, g, w);
       q4_put(XA, dl, g, c, w);
+      if (tx_dirty) {   // (wave-uniform) the segment's last_X changed at the jump just reversed
+        put_source();
+        tx_dirty = false;
+      }
       Q4_STAMP();
-      block_lds_barrier();                                   // (3) delta1
+      block_lds_barrier();                                   // (3) delta1, last_X
       Q4_STAMP();
       split_get<M::QW>(XA, dv, g, c);
       q4_gathered();
@@ -848,6 +939,9 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
       }
       Q4_STAMP();
       Q4_STAMP_PRINT("bwd");
+    };
+    if (k < a.K) {
+      if (k & 1) euler_step(Set1{}); else euler_step(Set0{});
     }
     // ---- reverse the jump applied right before step k
     while (i >= 0 && kj == k) {
@@ -858,21 +952,15 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
         float hn[4], hp[4], x[4], m[4], y[4], ybj[4], dy[4], dybj[4], dh[4], lam_hn[4], lam_new[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int uh = uo[r] < H ? uo[r] : 0, ud = uo[r] < D ? uo[r] : 0;
-          const float v0 = a.ltraj[((size_t)k * a.B + b) * H + uh], v1 = a.h_end[(size_t)r_ * H + uh];
-          const float v2 = a.X[(size_t)r_ * D + ud], v4 = a.y_row[(size_t)r_ * DO + ud],
-                      v5 = a.ybj_row[(size_t)r_ * DO + ud];
+          // the state after the jump = the state before step k: in registers unless k == K
+          float v0 = h_cur[r];
+          if (k >= a.K) v0 = a.ltraj[((size_t)k * a.B + b) * H + (uo[r] < H ? uo[r] : 0)];
           hn[r] = uo[r] < H ? v0 : 0.0f;
-          hp[r] = uo[r] < H ? v1 : 0.0f;
-          x[r] = uo[r] < D ? v2 : 0.0f;
-          y[r] = uo[r] < D ? v4 : 0.0f;
-          ybj[r] = uo[r] < D ? v5 : 0.0f;
-          if constexpr (C::MASKED) {
-            const float v3 = a.M[(size_t)r_ * D + ud];
-            m[r] = uo[r] < D ? v3 : 0.0f;
-          } else {
-            m[r] = uo[r] < D ? 1.0f : 0.0f;
-          }
+          hp[r] = uo[r] < H ? Rhp[r] : 0.0f;
+          x[r] = uo[r] < D ? Rx[r] : 0.0f;
+          y[r] = uo[r] < D ? Ry[r] : 0.0f;
+          ybj[r] = uo[r] < D ? Rybj[r] : 0.0f;
+          m[r] = uo[r] < D ? (C::MASKED ? Rm[r] : 1.0f) : 0.0f;
         }
         if constexpr (C::MASKED) {   // stage lx for the gather below (own in0 tiles -> rows)
 #pragma unroll
@@ -993,11 +1081,10 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
         for (int j = 0; j < NB1; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) lx[j][r] = has ? 0.0f : lx[j][r];
-        const int nsrc = a.item_prev[r_];
-        const int src2 = has ? nsrc : src;
-        load_source(src2, has);
-        src_i = has ? (src2 >= 0 ? a.t_of_row[src2 >= 0 ? src2 : 0] : -1) : src_i;
+        const int src2 = has ? src_pp : src;
+        load_rows(src2, has);
         src = src2;
+        tx_dirty = true;
       }
       --i;
     }

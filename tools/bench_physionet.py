@@ -6,7 +6,7 @@ from njode_amd import _lib, models, synthetic_physionet  # noqa: E402
 NN = ((50, 'tanh'), (50, 'tanh'))
 for B in (50, 800):
     cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
-               use_rnn=False, bias=True, dropout_rate=0.0,
+               use_rnn=False, bias=True, dropout_rate=float(os.environ.get('DROPOUT', '0.0')),
                options={'masked': True, 'device_outputs': True})
     b = synthetic_physionet.make_batch(batch_size=B, seed=0)
     torch.manual_seed(0)
@@ -23,6 +23,6 @@ for B in (50, 800):
     el = time.perf_counter() - t0
     _lib.profile_enable(False)
     k = {n: round(v[1] / v[0], 3) for n, v in _lib.profile_read().items()}
-    print(json.dumps({'case': 'config5-kernels', 'B': B, 'n_times': len(b['times']),
+    print(json.dumps({'case': 'config5-kernels', 'dropout': float(os.environ.get('DROPOUT', '0.0')), 'B': B, 'n_times': len(b['times']),
                       'n_obs': int(b['time_ptr'][-1]), 'step_ms': round(el * 1e3, 2),
                       'kernel_ms': k}), flush=True)
