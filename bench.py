@@ -136,9 +136,11 @@ def measured_traffic(kernel, n_paths, dropout):
     FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `python bench.py` (recipe: profiles/README.md),
     and records the workload it was taken on.  Returned only when that workload is the one
     being benchmarked, else None (a counter cannot be collected inside this process).
-    Units: rocprofv3 reports KiB; the kernel's accesses are 4-byte, i.e. outside the
-    calibrated (16 B / lane) regime of MI355X_MICROARCH.md's x2 FETCH_SIZE correction, so the
-    raw sum is reported."""
+    Units: rocprofv3 reports KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
+    the bytes of a coalesced streaming read, WRITE_SIZE is exact -- calibrated on this path's own
+    pattern (one dword per lane, 256 B per wave access): the forward's WRITE_SIZE equals the
+    bytes it stores (activations + checkpoints, 844 MB), and the backward, which reads those
+    same bytes back, shows FETCH_SIZE = 0.56x of them.  Reported: 2 x FETCH_SIZE + WRITE_SIZE."""
     try:
         with open(PMC_SUMMARY) as f:
             d = json.load(f)
@@ -150,7 +152,7 @@ def measured_traffic(kernel, n_paths, dropout):
     k = d.get(kernel, {})
     if k.get('FETCH_SIZE') is None or k.get('WRITE_SIZE') is None:
         return None, None
-    return int((k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024), wl.get('command')
+    return int((2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024), wl.get('command')
 
 
 def small_batch_ms(model, opt, dev, dt, T, sizes=(100, 200), steps=30):
