@@ -126,7 +126,12 @@ int njode_supported(const NjodeDims* dims);
 size_t njode_param_count(const NjodeDims* dims);
 
 /* Bytes of workspace njode_forward_f32 / njode_backward_f32 need for a batch of
- * this size (upper bound; n_steps/n_times as in NjodeSchedule). */
+ * this size (upper bound; n_steps/n_times as in NjodeSchedule).  With NJODE_C_SAVE_BWD the
+ * workspace also holds what the backward reads back: the state before every Euler step
+ * (H floats per path and step) and -- matrix-core shapes -- the ODE network's hidden
+ * activations of every step (8 ceil((width + 1) / 4) floats per path and step, 416 B for
+ * width 50: 845 MB for 20 000 paths x 100 steps; masked shapes 8 KB per 16 paths and step).
+ * The same call_flags must be passed here, to the forward and to the backward of one step. */
 int njode_workspace_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_obs,
                           int32_t n_times, int32_t n_steps, int32_t call_flags,
                           size_t* out);

@@ -129,7 +129,8 @@ template <class S, int NB1> struct Q4AdjReg {
 // the transposed products only (the sweep's Euler steps read the forward's activations)
 template <class S, int NB1> struct Q4AdjStep {
   float B3[S::QO], B2[S::QW], B1[NB1][S::QW];
-  NJ_DEV void load(const float* frag, int w, int lane) {
+  // input-gradient tiles: j = 0 -> tile w, j >= 1 -> tile t1 + w + 4 (j - 1)
+  NJ_DEV void load(const float* frag, int w, int lane, int t1) {
     static_assert(S::MT1 == 4, "four hidden tiles, one per wave");
 #pragma unroll
     for (int q = 0; q < S::QO; ++q) B3[q] = frag[(S::B3 + w * S::QO + q) * 64 + lane];
@@ -137,7 +138,8 @@ template <class S, int NB1> struct Q4AdjStep {
     for (int q = 0; q < S::QW; ++q) B2[q] = frag[(S::B2 + w * S::QW + q) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < NB1; ++j) {
-      const int t = w + 4 * j < S::MTI ? w + 4 * j : 0;
+      const int tj = j == 0 ? w : t1 + w + 4 * (j - 1);
+      const int t = tj < S::MTI ? tj : 0;
 #pragma unroll
       for (int q = 0; q < S::QW; ++q) B1[j][q] = frag[(S::B1 + t * S::QW + q) * 64 + lane];
     }
@@ -300,10 +302,19 @@ NJ_DEV void q4_delta_stored(const f32x4& acc, const float (&al)[4], float (&dl)[
 template <bool DROP>
 NJ_DEV void q4_row_keep(const KArgs& a, unsigned long long gid, uint32_t tkey, uint32_t net, int g, int w,
                         uint32_t& k1, uint32_t& k2) {
-  uint32_t f1, f2;
-  row_keep_bits<DROP>(a, gid, tkey, net, g, 16, f1, f2);
-  k1 = (f1 >> (4 * w)) & 15u;
-  k2 = (f2 >> (4 * w)) & 15u;
+  // row_keep_bits (njode_mfma_rows.h) draws 16 bits = 8 words per layer; this wave's bits
+  // 4w .. 4w+3 are words 2w, 2w+1 of each layer: the other words are stepped over
+  k1 = k2 = 0;
+  if constexpr (DROP) {
+    uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1), tkey, net);
+    auto skip = [&](int n) {
+      for (int i_ = 0; i_ < n; ++i_) { st ^= st << 13; st ^= st >> 17; st ^= st << 5; }
+    };
+    skip(2 * w);
+    k1 = keep_bits<4>(st, a.dc.thr16);
+    skip(6);
+    k2 = keep_bits<4>(st, a.dc.thr16);
+  }
 }
 template <class C, bool DROP>
 NJ_DEV void q4_ode_keep(const KArgs& a, unsigned long long gid, int k, int g, int w, uint32_t& k1, uint32_t& k2) {
@@ -696,7 +707,12 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   using DS = typename DecS<C>::type;
   using L = Q4Lds<C>;
   constexpr int D = C::D, H = C::H, DO = C::DO;
-  constexpr int NB1 = (M::MTB1 + 3) / 4;   // in0 gradient tiles per wave
+  // Input-gradient tiles of the ODE network (in0 units [h (H), x (D), ..]): the h tiles (wave w:
+  // tile w) every step; the x tiles T0X .. MTB1-1 (wave w: tile T0X + w) ONCE PER JUMP -- the
+  // input x of a segment is constant, so sum_steps W1x^T delta1 = W1x^T (sum_steps delta1):
+  // the sweep accumulates delta1 and the product waits for the jump
+  constexpr int T0X = H / 16, NB1 = 2;
+  static_assert(M::MTB1 - T0X <= 4 && M::MTH <= 4, "one x tile and one h tile per wave");
   static_assert((D + 15) / 16 <= 4 && DS::MTI <= 4, "one input-gradient tile per wave for the row networks");
   __shared__ __attribute__((aligned(16))) float lds_raw[L::ADJ_FLOATS];
   lfp XA = (lfp)lds_raw, XB = XA + XFLOATS, XD = XB + XFLOATS, HN = XD + XFLOATS, IN = HN + XFLOATS,
@@ -707,7 +723,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   Q4AdjStep<OS, NB1> Fo;
   Q4AdjLds<ES> Fe;
   Q4AdjReg<DS, 1> Fd;
-  Fo.load(a.frag, w, lane);
+  Fo.load(a.frag, w, lane, T0X);
   Fe.load((lfp)lds_raw + L::IMAGES + w * Q4AdjLds<ES>::NVEC * 64, a.frag_enc, w, lane);
   Fd.load(a.frag_dec, w, lane);
   __syncthreads();
@@ -725,11 +741,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   for (int r = 0; r < 4; ++r) uo[r] = 16 * w + 4 * r + g;
 
   float lam[4] = {0.f, 0.f, 0.f, 0.f};   // adjoint of h, own units
-  float lx[NB1][4];                      // gradient w.r.t. the ODE input, in0 tiles w, w + 4, ...
-#pragma unroll
-  for (int j = 0; j < NB1; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lx[j][r] = 0.0f;
+  float d1acc[4] = {0.f, 0.f, 0.f, 0.f};   // sum of delta1 over the steps of the segment, own units
   // The row this path reverses next (`src`), what the sweep needs of it (its time index, its
   // predecessor row, h before the jump, X, M, y, y_bj: own units), loaded when `src` is assigned --
   // under the lanes' exec mask, so nothing waits for these loads before the jump that uses them.
@@ -910,6 +922,10 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
       q4_gathered();
       acc = q4_dot<M::QW>([&](int q) { return Fo.b2(q); }, dv);
       q4_delta_stored<C::W, C::ACT, DROP>(acc, a1l, dl, a.dc.inv_keep, a.keep, g, w);
+      if constexpr (C::MASKED) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d1acc[r] += dl[r];
+      }
       q4_put(XA, dl, g, c, w);
       if (tx_dirty) {   // (wave-uniform) the segment's last_X changed at the jump just reversed
         put_source();
@@ -920,22 +936,11 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
       Q4_STAMP();
       split_get<M::QW>(XA, dv, g, c);
       q4_gathered();
-      // in0 units: [h (H), x (D), ...]; both are tanh'd inputs whose values sit in the image
+      // d/dh of the tanh'd state input: tile w for w < MTH
+      if (w < M::MTH) {
+        const f32x4 din = q4_dot<M::QW>([&](int q) { return Fo.b1(0, q); }, dv);
 #pragma unroll
-      for (int j = 0; j < NB1; ++j) {
-        if (w + 4 * j < M::MTB1) {
-          const f32x4 din = q4_dot<M::QW>([&](int q) { return Fo.b1(j, q); }, dv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int u = 16 * (w + 4 * j) + 4 * r + g;
-            // (rows < H are being rewritten by faster waves for the next step: the own register)
-            const float tx_ = IN[(u < H ? H : u) * IMG_STRIDE + c];
-            const float tv = (j == 0 && u < H) ? th[r] : tx_;
-            const float gq = din[r] * (1.0f - tv * tv);
-            if (j == 0) lam[r] += u < H ? gq : 0.0f;
-            if constexpr (C::MASKED) lx[j][r] += (u >= H && u < H + D) ? gq : 0.0f;
-          }
-        }
+        for (int r = 0; r < 4; ++r) lam[r] += uo[r] < H ? din[r] * (1.0f - th[r] * th[r]) : 0.0f;
       }
       Q4_STAMP();
       Q4_STAMP_PRINT("bwd");
@@ -962,13 +967,23 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
           ybj[r] = uo[r] < D ? Rybj[r] : 0.0f;
           m[r] = uo[r] < D ? (C::MASKED ? Rm[r] : 1.0f) : 0.0f;
         }
-        if constexpr (C::MASKED) {   // stage lx for the gather below (own in0 tiles -> rows)
+        if constexpr (C::MASKED) {
+          // gradient w.r.t. the segment's input x (the prediction at this row): W1x^T applied to
+          // the accumulated delta1, times tanh'; staged by in0 unit for the gather below
+          float dacc[M::QW];
+          q4_put(XD, d1acc, g, c, w);   // (XD: nobody reads it between the last barrier and here)
+          block_lds_barrier();
+          split_get<M::QW>(XD, dacc, g, c);
+          q4_gathered();
+          if (T0X + w < M::MTB1) {
+            const f32x4 din = q4_dot<M::QW>([&](int q) { return Fo.b1(1, q); }, dacc);
 #pragma unroll
-          for (int j = 0; j < NB1; ++j)
-            if (w + 4 * j < M::MTB1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) LX[(16 * (w + 4 * j) + 4 * r + g) * IMG_STRIDE + c] = lx[j][r];
+            for (int r = 0; r < 4; ++r) {
+              const int u = 16 * (T0X + w) + 4 * r + g;
+              const float tv = IN[(u >= H && u < H + D ? u : H) * IMG_STRIDE + c];
+              LX[u * IMG_STRIDE + c] = (u >= H && u < H + D) ? din[r] * (1.0f - tv * tv) : 0.0f;
             }
+          }
         }
         // gradient of compute_loss at this row
         {
@@ -1078,9 +1093,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) lam[r] = has ? lam_new[r] : lam[r];
 #pragma unroll
-        for (int j = 0; j < NB1; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lx[j][r] = has ? 0.0f : lx[j][r];
+        for (int r = 0; r < 4; ++r) d1acc[r] = has ? 0.0f : d1acc[r];
         const int src2 = has ? src_pp : src;
         load_rows(src2, has);
         src = src2;

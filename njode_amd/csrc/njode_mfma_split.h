@@ -193,6 +193,9 @@ NJ_DEV void split_hidden_layers(const SplitFrags<C, BWD>& F, lfp X1, const float
   block_lds_barrier();                               // (a) a1 of all four tiles is in X1
   float a1[M::Q1];
   split_get<M::Q1>(X1, a1, g, c);
+  // the gather is issued as one batch before the products: left alone the compiler emits
+  // ds_read2 -> s_waitcnt lgkmcnt(0) -> two MFMAs, seven LDS round trips in a row
+  __builtin_amdgcn_sched_barrier(0);
   // two accumulators halve the dependent chain of the 13 k-steps
   f32x4 acc0 = z, acc1 = z;
 #pragma unroll
@@ -410,6 +413,7 @@ NJ_DEV void ode_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
       // ---- layer 2: W2^T delta2 for the own units; dW2 row tile w
       float d2[M::QW];
       split_get<M::QW>(X2, d2, g, c);
+      __builtin_amdgcn_sched_barrier(0);   // (as in split_hidden_layers)
       f32x4 acc0 = z, acc1 = z;
 #pragma unroll
       for (int q = 0; q < M::QW; q += 2) {
@@ -602,6 +606,7 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
       // ---- layer 2: W2^T delta2 for the own units; dW2 row tile w
       float d2[M::QW];
       split_get<M::QW>(X2, d2, g, c);
+      __builtin_amdgcn_sched_barrier(0);   // (as in split_hidden_layers)
       f32x4 acc0 = z, acc1 = z;
 #pragma unroll
       for (int q = 0; q < M::QW; q += 2) {
