@@ -257,6 +257,8 @@ class NJODE(torch.nn.Module):
         self.input_current_t = options1.get('input_current_t', False)
         self.masked = options1.get('masked', False)
         self.device_outputs = bool(options1.get('device_outputs', False))
+        # route the forward through torch.ops.njode_amd.forward (njode_amd/ops.py)
+        self.torch_library_op = bool(options1.get('torch_library_op', False))
 
         self.ode_f = ODEFunc(input_size, hidden_size, ode_nn, dropout_rate, bias,
                              input_current_t=self.input_current_t)
@@ -526,6 +528,9 @@ class NJODE(torch.nn.Module):
         the Python int 0 when ``get_loss=False``."""
         want_grad = (torch.is_grad_enabled() and get_loss
                      and any(p.requires_grad for p in self.parameters()))
+        if self.torch_library_op and not return_path:
+            return self._forward_via_op(times, time_ptr, X, obs_idx, delta_t, T, start_X,
+                                        n_obs_ot, get_loss, until_T, M, want_grad)
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, return_path,
             get_loss, until_T, M, save_bwd=want_grad)
@@ -553,6 +558,23 @@ class NJODE(torch.nn.Module):
             loss_out = loss_out.cpu()       # reference harness calls .numpy() on it
         if return_path:
             return hT, loss_out, sched.path_t.copy(), path_h, path_y
+        return hT, loss_out
+
+    def _forward_via_op(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
+                        get_loss, until_T, M, want_grad):
+        """The same forward as one ``torch.library`` operator (``njode_amd/ops.py``)."""
+        from . import ops
+        self._ensure_flat()
+        hT, loss, _ = torch.ops.njode_amd.forward(
+            list(self._flat_params), start_X, X, obs_idx, n_obs_ot if get_loss else None,
+            M if self.masked else None, torch.as_tensor(np.asarray(times, dtype=np.float64)),
+            torch.as_tensor(np.asarray(time_ptr, dtype=np.int64)), float(delta_t), float(T),
+            ops.register_model(self), bool(get_loss), bool(until_T), bool(want_grad))
+        if not get_loss:
+            return hT, 0
+        loss_out = loss.reshape(())
+        if not self.device_outputs:
+            loss_out = loss_out.cpu()
         return hT, loss_out
 
     # -- fused training step (no autograd graph) ------------------------------------------

@@ -237,3 +237,23 @@ def test_library_loads_and_exports_declared_symbols():
     assert L.njode_workspace_bytes(ctypes.byref(d2), 100, 1000, 100, 100, 0,
                                    ctypes.byref(need)) == _lib.E_UNSUPPORTED
     assert b'compiled' in L.njode_last_error()
+
+
+def test_torch_library_operator_is_registered_with_a_fake_implementation():
+    """njode_amd/ops.py: torch.ops.njode_amd.forward exists (dispatcher-visible operator) and its
+    fake implementation gives the output shapes without touching a GPU."""
+    import njode_amd.ops as ops
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    schema = str(torch.ops.njode_amd.forward.default._schema)
+    assert 'Tensor[] params' in schema and '-> (Tensor, Tensor, Tensor)' in schema
+    nn50 = ((50, 'tanh'), (50, 'tanh'))
+    m = models.NJODE(input_size=1, hidden_size=10, output_size=1, ode_nn=nn50, readout_nn=nn50,
+                     enc_nn=nn50, use_rnn=False, bias=True, dropout_rate=0.0, options={})
+    mid = ops.register_model(m)
+    with FakeTensorMode():
+        hT, loss, cid = torch.ops.njode_amd.forward(
+            [torch.empty(3)], torch.empty(7, 1), torch.empty(20, 1),
+            torch.empty(20, dtype=torch.int64), torch.empty(7, dtype=torch.int32), None,
+            torch.empty(5, dtype=torch.float64), torch.empty(6, dtype=torch.int64), 0.01, 1.0,
+            mid, True, False, False)
+    assert tuple(hT.shape) == (7, 10) and tuple(loss.shape) == (1,) and cid.dim() == 0
