@@ -72,7 +72,12 @@ template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st
 template <class CC, bool DROP> static void launch_mfma_enc(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     const int n_tiles = cdiv(a.n_obs + a.B, 16);
-    k_encode_rows_mfma<CC, DROP><<<n_tiles < 2048 ? n_tiles : 2048, 64, 0, st>>>(a);
+    // one-wave blocks, 64 VGPRs: four waves per SIMD hide the row gathers (obs_idx -> path,
+    // t_of_row -> k_jump, X) each tile starts with: 51 -> 37 us for 219 470 rows (the step time
+    // does not move: the plan on the helper stream is the critical path beside this kernel);
+    // NJODE_ENC_BLOCKS overrides (A/B)
+    static const int enc_blocks = getenv("NJODE_ENC_BLOCKS") ? atoi(getenv("NJODE_ENC_BLOCKS")) : 4096;
+    k_encode_rows_mfma<CC, DROP><<<n_tiles < enc_blocks ? n_tiles : enc_blocks, 64, 0, st>>>(a);
   }
 }
 template <class CC, bool DROP> static void launch_mfma_jump(const KArgs& a, hipStream_t st) {
