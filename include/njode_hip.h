@@ -78,6 +78,9 @@ typedef struct NjodeDims {
                                    after the last jump) in NJODE_C_SCHED_TAIL; the library then
                                    never reads the host schedule arrays to choose the plan, so
                                    njode_backward*_f32 may be called after they were reused     */
+#define NJODE_C_PLAN_READY 0x80  /* NjodeBatch.plan holds the schedule copy and the execution plan,
+                                   built ahead of time by njode_plan_f32 (below)              */
+#define NJODE_C_NEED_HT 0x100    /* (njode_plan_f32) the forward will be asked for hT         */
 #define NJODE_C_SCHED_TAIL 0x40  /* (with SCHED_KNOWN) k_jump[n_times-1] < n_steps             */
 
 /*
@@ -115,6 +118,8 @@ typedef struct NjodeBatch {
   float loss_batch_size;   /* the `batch_size` in compute_loss (models.py:106); for a */
                            /* data-parallel shard pass the GLOBAL batch size          */
   int64_t path_id_offset;  /* global id of path 0 (dropout streams are keyed by it)   */
+  const void* plan;        /* NJODE_C_PLAN_READY: the buffer njode_plan_f32 filled for */
+                           /* this batch, schedule and call_flags; else ignored (NULL) */
 } NjodeBatch;
 
 /* ---- queries ----------------------------------------------------------------- */
@@ -135,6 +140,23 @@ size_t njode_param_count(const NjodeDims* dims);
 int njode_workspace_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_obs,
                           int32_t n_times, int32_t n_steps, int32_t call_flags,
                           size_t* out);
+
+/*
+ * Plan ahead (optional).  The execution plan of a call -- device copy of the schedule, rows
+ * linked per path, segments sorted by length, trajectory layout: ~0.12 ms of small
+ * latency-bound kernels at 20 000 paths -- depends on the batch and the schedule only, not on
+ * the parameters.  A training loop that has batch i+1 in hand while step i runs can build it on
+ * another stream, beside step i's kernels: njode_plan_f32 writes it into a caller-owned buffer
+ * of njode_plan_bytes bytes, and the forward AND the backward of that batch are then called
+ * with NJODE_C_PLAN_READY and NjodeBatch.plan = that buffer (which they only read), skipping
+ * the plan stage.  Same dims, batch arrays, schedule and call_flags (NJODE_C_PLAN_READY aside)
+ * as those calls; NJODE_C_NEED_HT if the forward will be given hT != NULL.  The host schedule
+ * arrays must stay valid until `stream` has executed the call (an asynchronous copy).
+ */
+int njode_plan_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_obs,
+                     int32_t n_times, int32_t n_steps, int32_t call_flags, size_t* out);
+int njode_plan_f32(const NjodeDims* dims, const NjodeBatch* batch, const NjodeSchedule* sched,
+                   int32_t call_flags, void* plan, size_t plan_bytes, njodeStream_t stream);
 
 /* ---- the hot path ------------------------------------------------------------ */
 

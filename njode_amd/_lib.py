@@ -18,8 +18,10 @@ ACT_TANH, ACT_RELU = 0, 1
 F_MASKED, F_INPUT_CURRENT_T, F_RESIDUAL, F_LOSS_EASY, F_USE_RNN = 0x1, 0x2, 0x4, 0x8, 0x10
 C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD, C_LOSS_IN_BWD = 0x1, 0x2, 0x4, 0x8, 0x10
 C_SCHED_KNOWN, C_SCHED_TAIL = 0x20, 0x40
+C_PLAN_READY, C_NEED_HT = 0x80, 0x100
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
+           'njode_plan_bytes', 'njode_plan_f32',
            'njode_forward_f32', 'njode_backward_f32', 'njode_backward_loss_f32',
            'njode_adam_step_f32',
            'njode_last_error', 'njode_build_info', 'njode_profile_enable',
@@ -49,7 +51,8 @@ class NjodeBatch(C.Structure):
     _fields_ = [('batch_size', C.c_int32), ('n_obs', C.c_int32),
                 ('start_X', C.c_void_p), ('X', C.c_void_p), ('M', C.c_void_p),
                 ('obs_idx', C.c_void_p), ('n_obs_ot', C.c_void_p),
-                ('loss_batch_size', C.c_float), ('path_id_offset', C.c_int64)]
+                ('loss_batch_size', C.c_float), ('path_id_offset', C.c_int64),
+                ('plan', C.c_void_p)]
 
 
 class NjodeSde(C.Structure):
@@ -92,6 +95,11 @@ def lib():
     L.njode_workspace_bytes.argtypes = [C.POINTER(NjodeDims), i32, i32, i32, i32, i32,
                                         C.POINTER(sz)]
     L.njode_workspace_bytes.restype = C.c_int
+    L.njode_plan_bytes.argtypes = [C.POINTER(NjodeDims), i32, i32, i32, i32, i32, C.POINTER(sz)]
+    L.njode_plan_bytes.restype = C.c_int
+    L.njode_plan_f32.argtypes = [C.POINTER(NjodeDims), C.POINTER(NjodeBatch),
+                                 C.POINTER(NjodeSchedule), i32, vp, sz, vp]
+    L.njode_plan_f32.restype = C.c_int
     L.njode_forward_f32.argtypes = [C.POINTER(NjodeDims), vp, C.POINTER(NjodeBatch),
                                     C.POINTER(NjodeSchedule), i32, f32, f32, u64,
                                     vp, vp, vp, vp, vp, sz, vp]

@@ -141,6 +141,14 @@ def build(force=False, jobs=None, verbose=True):
                 or open(stamp).read() != t[2])
 
     todo = [t for t in tasks if stale(t)]
+    parts_only = os.environ.get('NJODE_PARTS_ONLY', '').strip()   # maintainer aid, e.g. "0": a change
+    if parts_only:                                                 # that only touches those parts
+        keep = tuple('_{}.o'.format(x) for x in parts_only.split(',')) + ('api.o', 'producer.o')
+        for t in todo:
+            if not t[0].endswith(keep) and os.path.exists(t[0]):
+                with open(t[0] + '.stamp', 'w') as f:
+                    f.write(t[2])
+        todo = [t for t in todo if t[0].endswith(keep) or not os.path.exists(t[0])]
     if not todo and os.path.exists(LIB) and not force:
         if verbose:
             print('[njode_amd.build] up to date:', LIB)

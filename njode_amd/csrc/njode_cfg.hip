@@ -148,16 +148,24 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
   if constexpr (C::MASKED || C::RNN) {
     return hipErrorNotSupported;
   } else {
+    // pack + encoder rows: on the call's helper stream when there is one (they only need
+    // t_of_row; the plan kernels already sit on `st`), else in line
+    const SideInfo* side = (const SideInfo*)a.plan_ready;
+    hipStream_t s2 = side ? side->st : st;
+    if (side) (void)hipStreamWaitEvent(s2, side->e0, 0);
     if constexpr (ODE == ODE_MFMA) {
-      ProfScope ps("k_pack_frags", st);
-      launch_pack_frags<C>(a, st);
+      ProfScope ps("k_pack_frags", s2);
+      launch_pack_frags<C>(a, s2);
     }
     {
-      ProfScope ps(ODE == ODE_MFMA ? "k_encode_rows_mfma" : "k_encode_rows", st);
-      if constexpr (ODE == ODE_MFMA) launch_mfma_enc<C, DROP>(a, st);
-      else k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, st>>>(a);
+      ProfScope ps(ODE == ODE_MFMA ? "k_encode_rows_mfma" : "k_encode_rows", s2);
+      if constexpr (ODE == ODE_MFMA) launch_mfma_enc<C, DROP>(a, s2);
+      else k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, s2>>>(a);
     }
-    if (a.plan_ready) (void)hipStreamWaitEvent(st, (hipEvent_t)a.plan_ready, 0);
+    if (side) {
+      (void)hipEventRecord(side->e1, s2);
+      (void)hipStreamWaitEvent(st, side->e1, 0);
+    }
     {
       ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma" : "k_ode_fwd_items", st);
       launch_ode_fwd<DROP, false, ODE>(a, st);

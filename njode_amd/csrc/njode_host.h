@@ -42,6 +42,16 @@ struct CfgOps {
   int seg_mfma;         // the segment plan has matrix-core kernels for this shape
 };
 
+// Helper stream of one forward call (KArgs::plan_ready points at it, host side only): the
+// fragment packing and the encoder rows run there, BESIDE the plan kernels on the caller's
+// stream -- the plan is the longer chain, so it stays where no cross-stream hop delays it.
+// e0: recorded on the caller's stream once t_of_row exists (and everything before the call is
+// done); e1: recorded on the helper stream after the encoder rows.
+struct SideInfo {
+  hipStream_t st;
+  hipEvent_t e0, e1;
+};
+
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events
 // recorded on the launch stream around each kernel.  Defined in njode_api.hip.
 void prof_mark(const char* name, hipStream_t st, bool begin);

@@ -198,6 +198,17 @@ class _Call:
             slot[1] = False
 
 
+class _Plan:
+    """A plan built ahead by ``NJODE.prefetch_plan``; its buffer returns to the model's pool
+    when the last call that reads it is gone."""
+    __slots__ = ('buf', 'done', 'flags', 'sizes', 'keep', 'pool')
+
+    def __del__(self):
+        pool, buf = getattr(self, 'pool', None), getattr(self, 'buf', None)
+        if pool is not None and buf is not None and len(pool) < 4:
+            pool.append(buf)
+
+
 class _NJODEFunction(torch.autograd.Function):
     """loss = F(params); backward = exact discrete adjoint (njode_backward_f32)."""
 
@@ -295,6 +306,9 @@ class NJODE(torch.nn.Module):
         self._ring = None
         self._ws_pool = []
         self._dims = None
+        self._plans = {}
+        self._plan_pool = []
+        self._plan_stream = None
 
     # -- reference API ----------------------------------------------------------------
     def weight_decay_step(self):
@@ -415,7 +429,7 @@ class NJODE(torch.nn.Module):
             call.ws_slot = None
 
     def _make_call(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
-                   return_path, get_loss, until_T, M, save_bwd):
+                   return_path, get_loss, until_T, M, save_bwd, plan_key=None, plan_only=False):
         L = _lib.lib()
         dev = start_X.device
         if dev.type != 'cuda':
@@ -461,13 +475,23 @@ class NJODE(torch.nn.Module):
         gb = float(self.dp_global_batch if self.dp_global_batch else B)
         cb = _lib.NjodeBatch(B, n_obs, start_X.data_ptr(), X.data_ptr() if n_obs else None,
                              M_ptr, obs_idx_d.data_ptr() if n_obs else None, n_ptr, gb,
-                             int(self.dp_path_offset))
+                             int(self.dp_path_offset), None)
         flags = ((_lib.C_TRAIN if self.training else 0) | (_lib.C_GET_LOSS if get_loss else 0)
                  | (_lib.C_RETURN_PATH if return_path else 0)
                  | (_lib.C_SAVE_BWD if save_bwd else 0)
                  # the plan decision travels with the call: the backward never re-reads the
                  # pinned schedule buffer, which the ring may have handed to a later forward
                  | _lib.C_SCHED_KNOWN | (_lib.C_SCHED_TAIL if sched.has_tail() else 0))
+        if plan_only:   # prefetch_plan: the structs of the call, nothing allocated or counted
+            return dims, cb, cs, flags, keep + [pinned], slot_i, (B, n_obs, nt, K)
+        plan = None
+        if plan_key is not None:
+            plan = self._take_plan(plan_key, flags, B, n_obs, nt, K)
+        if plan is not None:
+            cb.plan = plan.buf.data_ptr()
+            flags |= _lib.C_PLAN_READY | (plan.flags & _lib.C_NEED_HT)
+            torch.cuda.current_stream().wait_event(plan.done)
+            keep.append(plan)
         need = ctypes.c_size_t(0)
         _lib.check(L.njode_workspace_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
                                            ctypes.byref(need)))
@@ -519,6 +543,69 @@ class NJODE(torch.nn.Module):
             ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
             grad_loss.data_ptr(), grad_flat.data_ptr(), call.ws.data_ptr(), call.ws.numel(),
             stream.cuda_stream))
+
+    # -- plan ahead (njode_plan_f32) --------------------------------------------------------
+    def prefetch_plan(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
+                      M=None, need_hT=None):
+        """Build the execution plan of a coming ``loss_and_grad`` / training ``forward`` call
+        for this batch NOW, on a helper stream, beside whatever the current stream is running
+        (``include/njode_hip.h``: ``njode_plan_f32``).  The plan depends on the batch and the
+        schedule only, not on the parameters; the call that later receives the same batch
+        (same ``obs_idx`` tensor and ``time_ptr`` array, in the order they were prefetched)
+        picks it up and skips its own plan stage.  Call it for batch i+1 right before the
+        step on batch i.  ``need_hT``: the coming call returns hT (default: masked models)."""
+        need_hT = self.masked if need_hT is None else bool(need_hT)
+        dims, cb, cs, flags, keep, slot_i, (B, n_obs, nt, K) = self._make_call(
+            times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False, M,
+            save_bwd=True, plan_only=True)
+        if need_hT:
+            flags |= _lib.C_NEED_HT
+        L = _lib.lib()
+        need = ctypes.c_size_t(0)
+        _lib.check(L.njode_plan_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
+                                      ctypes.byref(need)))
+        dev = start_X.device
+        buf = None
+        for cand in self._plan_pool:
+            if cand.device == dev and cand.numel() >= need.value:
+                buf = cand
+                self._plan_pool.remove(cand)
+                break
+        if buf is None:
+            buf = torch.empty(int(need.value * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        if self._plan_stream is None:
+            self._plan_stream = torch.cuda.Stream(device=dev)
+        side = self._plan_stream
+        side.wait_stream(torch.cuda.current_stream())   # the batch's arrays are ready by now
+        with torch.cuda.stream(side):
+            rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs), flags,
+                                  buf.data_ptr(), buf.numel(), side.cuda_stream)
+            self._ring.release_after(slot_i, side)
+            _lib.check(rc)
+            done = torch.cuda.Event()
+            done.record(side)
+        plan = _Plan()
+        plan.buf, plan.done, plan.flags, plan.sizes, plan.keep = buf, done, flags, (B, n_obs, nt, K), keep
+        plan.pool = self._plan_pool
+        self._plans.setdefault(self._plan_key(obs_idx, time_ptr), []).append(plan)
+
+    @staticmethod
+    def _plan_key(obs_idx, time_ptr):
+        return (id(obs_idx), id(time_ptr))
+
+    def _take_plan(self, key, flags, B, n_obs, nt, K):
+        """Oldest prefetched plan of this batch, if it was made for this kind of call."""
+        q = self._plans.get(key)
+        if not q:
+            return None
+        plan = q[0]
+        want = flags & ~(_lib.C_LOSS_IN_BWD | _lib.C_PLAN_READY)
+        if plan.sizes != (B, n_obs, nt, K) or (plan.flags & ~_lib.C_NEED_HT) != want:
+            return None
+        q.pop(0)
+        if not q:
+            del self._plans[key]
+        return plan
 
     # -- forward -------------------------------------------------------------------------
     def forward(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
@@ -590,7 +677,7 @@ class NJODE(torch.nn.Module):
         grad = self.flat_grad()
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
-            M, save_bwd=True)
+            M, save_bwd=True, plan_key=self._plan_key(obs_idx, time_ptr) if self._plans else None)
         dev = start_X.device
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         # hT is only skipped on the segment plan (unmasked): there it would cost an extra

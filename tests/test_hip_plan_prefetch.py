@@ -1,0 +1,56 @@
+"""njode_plan_f32 / NJODE.prefetch_plan: a plan built ahead on a helper stream is the plan the
+call would have built itself -- loss and gradient are bit-identical, for the segment plan
+(demo shape, counting-sort and Onesweep sizes) and the masked lockstep plan."""
+import pytest
+import torch
+
+from hip_util import bs_batch, demo_cfg, to_dev
+from njode_amd import models, synthetic_physionet
+
+pytestmark = pytest.mark.gpu
+NN = ((50, 'tanh'), (50, 'tanh'))
+
+
+def _step(m, args, kw, prefetch, left=0):
+    m._step_counter = 3
+    if prefetch:
+        m.prefetch_plan(*args, **kw)
+        assert m._plans
+    _, loss = m.loss_and_grad(*args, **kw)
+    assert sum(len(q) for q in m._plans.values()) == left   # one prefetched plan was picked up
+    return float(loss), m.flat_grad().clone()
+
+
+@pytest.mark.parametrize('n_paths', [300, 3000])
+def test_prefetched_plan_gives_identical_results_on_the_segment_plan(n_paths):
+    cfg = demo_cfg(dropout=0.1, device_outputs=True)
+    torch.manual_seed(0)
+    m = models.NJODE(**cfg).cuda().train()
+    b, meta = bs_batch(n_paths, seed=4)
+    b = to_dev(b)
+    obs_idx = b['obs_idx'].cuda().int()
+    args = (b['times'], b['time_ptr'], b['X'], obs_idx, meta['dt'], meta['maturity'], b['start_X'],
+            b['n_obs_ot'])
+    l0, g0 = _step(m, args, {}, False)
+    l1, g1 = _step(m, args, {}, True)
+    assert l1 == l0 and torch.equal(g1, g0)
+    # two plans in flight, consumed in order
+    m.prefetch_plan(*args)
+    l2, g2 = _step(m, args, {}, True, left=1)
+    l3, g3 = _step(m, args, {}, False)
+    assert (l2, l3) == (l0, l0) and torch.equal(g2, g0) and torch.equal(g3, g0)
+
+
+def test_prefetched_plan_gives_identical_results_on_the_masked_plan():
+    cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
+               use_rnn=False, bias=True, dropout_rate=0.0, options={'masked': True, 'device_outputs': True})
+    b = synthetic_physionet.make_batch(batch_size=20, n_grid=120, n_obs_range=(3, 9), seed=3)
+    torch.manual_seed(0)
+    m = models.NJODE(**cfg).cuda().train()
+    obs_idx = b['obs_idx'].cuda().int()
+    args = (b['times'], b['time_ptr'], b['X'].cuda(), obs_idx, b['delta_t'], b['T'],
+            b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+    kw = {'M': b['M'].cuda()}
+    l0, g0 = _step(m, args, kw, False)
+    l1, g1 = _step(m, args, kw, True)
+    assert l1 == l0 and torch.equal(g1, g0)
