@@ -69,14 +69,16 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
           weight_decay=1., test_size=0.2, seed=398, device='cuda', fused=True,
           evaluate=False, shuffle_seed=0, log=print, max_steps_per_epoch=None,
           device_collate=False, model_path=None, model_id=1, save_every=1,
-          resume_training=False, load_best=False, **options):
+          resume_training=False, load_best=False, plan_ahead=True, **options):
     """Train on an in-memory dataset ``(stock_paths, observed_dates, nb_obs)`` with
     ``metadata`` as returned by ``data_utils.create_dataset``.  Returns
     ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch.
 
     ``device_collate=True`` uploads the dataset once and builds every training batch with the
     GPU collate (``device_data.DeviceDataset``): same batches bit for bit, without the
-    per-step host collate and host-to-device copies."""
+    per-step host collate and host-to-device copies.  ``plan_ahead`` (fused loop): collate one
+    batch ahead and build its execution plan beside the current step (same results bit for
+    bit)."""
     stock_paths, observed_dates, nb_obs = dataset_arrays
     delta_t, T = metadata['dt'], metadata['maturity']
     input_size = output_size = metadata['dimension']
@@ -151,10 +153,9 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
         if max_steps_per_epoch:
             n_steps = min(n_steps, max_steps_per_epoch)
         loss = None
-        for s in range(n_steps):
+        def prepare(s):
             idx = order[s * batch_size:(s + 1) * batch_size]
             lo, hi = parallel.shard_range(len(idx), world, rank)
-            parallel.configure_model(model, len(idx), lo)
             mine = idx[lo:hi]
             if len(mine) == 0:
                 d = dict(times=None, time_ptr=None, X=None, obs_idx=None, start_X=None,
@@ -165,6 +166,19 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                 b = data_utils.collate_arrays(stock_paths[mine], observed_dates[mine],
                                               nb_obs[mine], delta_t, funcs)
                 d = _device_batch(b, device)
+            return idx, lo, mine, d
+
+        nxt = prepare(0) if n_steps > 0 else None
+        for s in range(n_steps):
+            idx, lo, mine, d = nxt
+            # one batch ahead: the next batch is collated now, and (fused loop) its execution
+            # plan is built on a helper stream beside this step (NJODE.prefetch_plan)
+            nxt = prepare(s + 1) if s + 1 < n_steps else None
+            if plan_ahead and fused and nxt is not None and len(nxt[2]) > 0:
+                dn = nxt[3]
+                model.prefetch_plan(dn['times'], dn['time_ptr'], dn['X'], dn['obs_idx'], delta_t, T,
+                                    dn['start_X'], dn['n_obs_ot'])
+            parallel.configure_model(model, len(idx), lo)
             args = (d['times'], d['time_ptr'], d['X'], d['obs_idx'], delta_t, T, d['start_X'],
                     d['n_obs_ot'])
             optimizer.zero_grad()
