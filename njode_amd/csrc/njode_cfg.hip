@@ -55,18 +55,28 @@ template <bool ON, class CC> struct ActSize { static constexpr int value = 0; };
 template <class CC> struct ActSize<true, CC> { static constexpr int value = 8 * MF<CC>::Q1; };
 constexpr int ACT_FLOATS = ActSize<HAS_SPLIT, C>::value;   // stored activations: demo-family shapes
 
+// All fragment tables of the three networks in ONE launch instead of three in
+// front of the encoder rows (each of these launches costs ~5 us of a chain that sits on the
+// step's critical path once the plan is built ahead)
+template <class C, class ES, class DS>
+__global__ void k_pack_all(const float* __restrict__ P, float* __restrict__ frag, float* __restrict__ frag2,
+                           float* __restrict__ frag_enc, float* __restrict__ frag_dec, float ik) {
+  constexpr int N = MF<C>::NALL * 64, NE = ES::NALL * 64, ND = DS::NALL * 64;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < N) frag[idx] = ode_frag_value<C>(P, idx, 1.0f, 1.0f);
+  else if (idx < 2 * N) frag2[idx - N] = ode_frag_value<C>(P, idx - N, Ode2Scale<C>::S, ik);
+  else if (idx < 2 * N + NE) pack_net_value<typename C::Enc, ES>(P + C::OFF_ENC, frag_enc, idx - 2 * N);
+  else if (idx < 2 * N + NE + ND) pack_net_value<typename C::Dec, DS>(P + C::OFF_DEC, frag_dec, idx - 2 * N - NE);
+}
+
 // MFMA launches live in templates on the configuration so that `if constexpr` really
 // discards them for shapes the matrix-core kernels are not written for
 template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     using ES = typename EncS<CC>::type;
     using DS = typename DecS<CC>::type;
-    k_pack_frags12<CC><<<cdiv(2 * MF<CC>::NALL * 64, 256), 256, 0, st>>>(a.P, a.frag, a.frag2,
-                                                                          a.dc.inv_keep);
-    k_pack_net<typename CC::Enc, ES><<<cdiv(ES::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_ENC,
-                                                                             a.frag_enc);
-    k_pack_net<typename CC::Dec, DS><<<cdiv(DS::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_DEC,
-                                                                             a.frag_dec);
+    k_pack_all<CC, ES, DS><<<cdiv((2 * MF<CC>::NALL + ES::NALL + DS::NALL) * 64, 256), 256, 0, st>>>(
+        a.P, a.frag, a.frag2, a.frag_enc, a.frag_dec, a.dc.inv_keep);
   }
 }
 template <class CC, bool DROP> static void launch_mfma_enc(const KArgs& a, hipStream_t st) {

@@ -20,8 +20,7 @@ template <int IN_, int OUT_, int W_> struct MS {
 
 // A-fragments of all six products of one network (inputs in natural order)
 template <class NL, class S>
-__global__ void k_pack_net(const float* __restrict__ Pn, float* __restrict__ frag) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+NJ_DEV void pack_net_value(const float* __restrict__ Pn, float* __restrict__ frag, int idx) {
   if (idx >= S::NALL * 64) return;
   const int f = idx >> 6, l = idx & 63, g = l >> 4, c = l & 15;
   const float *W1 = Pn + NL::woff(0), *b1 = Pn + NL::boff(0), *W2 = Pn + NL::woff(1),
@@ -47,6 +46,10 @@ __global__ void k_pack_net(const float* __restrict__ Pn, float* __restrict__ fra
     if (ui < S::IN && uo < S::W) v = W1[uo * S::IN + ui];
   }
   frag[idx] = v;
+}
+template <class NL, class S>
+__global__ void k_pack_net(const float* __restrict__ Pn, float* __restrict__ frag) {
+  pack_net_value<NL, S>(Pn, frag, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Fragment providers.  Register sets (forward kernels: ~70 VGPRs) and LDS views

@@ -679,7 +679,7 @@ class NJODE(torch.nn.Module):
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
             M, save_bwd=True, plan_key=self._plan_key(obs_idx, time_ptr) if self._plans else None)
         dev = start_X.device
-        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)   # (always written: sum of the terms)
         # hT is only skipped on the segment plan (unmasked): there it would cost an extra
         # per-path tail evolve; the lockstep plan produces it anyway
         hT = (torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
