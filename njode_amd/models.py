@@ -620,7 +620,8 @@ class NJODE(torch.nn.Module):
                                         n_obs_ot, get_loss, until_T, M, want_grad)
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, return_path,
-            get_loss, until_T, M, save_bwd=want_grad)
+            get_loss, until_T, M, save_bwd=want_grad,
+            plan_key=self._plan_key(obs_idx, time_ptr) if self._plans else None)
         dev = start_X.device
         hT = torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
         loss = torch.zeros(1, dtype=torch.float32, device=dev) if get_loss else None

@@ -54,3 +54,28 @@ def test_prefetched_plan_gives_identical_results_on_the_masked_plan():
     l0, g0 = _step(m, args, kw, False)
     l1, g1 = _step(m, args, kw, True)
     assert l1 == l0 and torch.equal(g1, g0)
+
+
+def test_autograd_route_picks_a_prefetched_plan_up():
+    cfg = demo_cfg(dropout=0.0, device_outputs=True)
+    torch.manual_seed(0)
+    m = models.NJODE(**cfg).cuda().train()
+    b, meta = bs_batch(200, seed=5)
+    b = to_dev(b)
+    obs_idx = b['obs_idx'].cuda().int()
+    args = (b['times'], b['time_ptr'], b['X'], obs_idx, meta['dt'], meta['maturity'], b['start_X'],
+            b['n_obs_ot'])
+
+    def run(prefetch):
+        for p in m.parameters():
+            p.grad = None
+        if prefetch:
+            m.prefetch_plan(*args, need_hT=True)
+        hT, loss = m(*args)
+        loss.backward()
+        assert not m._plans
+        return hT.clone(), float(loss), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    h0, l0, g0 = run(False)
+    h1, l1, g1 = run(True)
+    assert l1 == l0 and torch.equal(h1, h0) and torch.equal(g1, g0)
