@@ -277,8 +277,11 @@ def main():
         step()
     timing = not args.no_kernel_timing
     sync()
+    # HIP events inside the timed region: around the DOMINANT kernel only (the ODE backward) --
+    # bracketing all six hot kernels costs ~3.5 % of the step.  The other kernels' times come
+    # from a second, untimed pass of the same K steps below (`kernel_ms`).
     if timing:
-        _lib.profile_enable(True)
+        _lib.profile_enable(2)
     opt.time_allreduce = distributed        # HIP events around the collective (device time)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -287,10 +290,17 @@ def main():
     elapsed_local = time.perf_counter() - t0
     opt.time_allreduce = False
     allreduce_ms = opt.allreduce_ms()
-    kern = {}
+    kern, kern_timed = {}, {}
     if timing:
         _lib.profile_enable(False)
-        kern = _lib.profile_read()
+        kern_timed = _lib.profile_read()          # the dominant kernel, live in the timed region
+        _lib.profile_enable(1)
+        for _ in range(args.steps):
+            step()
+        sync()
+        _lib.profile_enable(False)
+        kern = _lib.profile_read()                # all kernels, second pass (not timed)
+        kern.update(kern_timed)
     t = torch.tensor([elapsed_local], device=dev, dtype=torch.float64)
     per_rank = [elapsed_local]
     if distributed:
@@ -366,6 +376,9 @@ def main():
                     'achieved_executed': round(tf_e, 3),
                     'traffic': traffic, 'traffic_source': traffic_src,
                     'kernel_ms': round(dom_ms, 5),
+                    'kernel_ms_source': ('HIP events on the launch stream inside the timed region'
+                                         if dom in kern_timed else
+                                         'HIP events, second pass of the same steps'),
                     'algorithmic_flops': int(2 * strict * euler_steps),
                     'executed_useful_flops': int(2 * executed * euler_steps),
                     'note': 'achieved / frac = STRICT algorithmic work (SURVEY 8d: 14 600 flop per '

@@ -245,7 +245,8 @@ const char* njode_last_error(void);
  * every hot-path kernel launch is bracketed by hipEvents recorded on the launch
  * stream.  njode_profile_read synchronises the device and writes one line per
  * kernel, "<name> <launches> <total_ms>\n", then clears the records.  This is the
- * library's only process-global state.
+ * library's only process-global state.  on = 1: every kernel (twelve events per training step,
+ * ~3.5 % of a 1.1 ms step); on = 2: the ODE backward kernel only (two events).
  */
 int njode_profile_enable(int on);
 int njode_profile_read(char* out, size_t cap);

@@ -153,7 +153,8 @@ def build_info():
 
 
 def profile_enable(on=True):
-    check(lib().njode_profile_enable(1 if on else 0))
+    """True / 1: every kernel; 2: the ODE backward kernel only (cheap enough for a timed region)."""
+    check(lib().njode_profile_enable(int(on)))
 
 
 def profile_read():
