@@ -588,6 +588,13 @@ class NJODE(torch.nn.Module):
         plan.buf, plan.done, plan.flags, plan.sizes, plan.keep = buf, done, flags, (B, n_obs, nt, K), keep
         plan.pool = self._plan_pool
         self._plans.setdefault(self._plan_key(obs_idx, time_ptr), []).append(plan)
+        # plans nobody picks up (a prefetched batch that is then never stepped on) must not pile
+        # up: keep the four newest
+        while sum(len(q) for q in self._plans.values()) > 4:
+            k0 = next(iter(self._plans))
+            self._plans[k0].pop(0)
+            if not self._plans[k0]:
+                del self._plans[k0]
 
     @staticmethod
     def _plan_key(obs_idx, time_ptr):
