@@ -77,8 +77,8 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
     ``device_collate=True`` uploads the dataset once and builds every training batch with the
     GPU collate (``device_data.DeviceDataset``): same batches bit for bit, without the
     per-step host collate and host-to-device copies.  ``plan_ahead`` (fused loop): collate one
-    batch ahead and build its execution plan beside the current step (same results bit for
-    bit)."""
+    batch ahead and, for local batches of 4 096 paths or more, build its execution plan beside
+    the current step (same results bit for bit)."""
     stock_paths, observed_dates, nb_obs = dataset_arrays
     delta_t, T = metadata['dt'], metadata['maturity']
     input_size = output_size = metadata['dimension']
@@ -168,13 +168,17 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                 d = _device_batch(b, device)
             return idx, lo, mine, d
 
+        # (NJODE_PLAN_AHEAD=0: A/B switch for the look-ahead)
+        plan_ahead = plan_ahead and os.environ.get('NJODE_PLAN_AHEAD', '1') != '0'
         nxt = prepare(0) if n_steps > 0 else None
         for s in range(n_steps):
             idx, lo, mine, d = nxt
             # one batch ahead: the next batch is collated now, and (fused loop) its execution
             # plan is built on a helper stream beside this step (NJODE.prefetch_plan)
             nxt = prepare(s + 1) if s + 1 < n_steps else None
-            if plan_ahead and fused and nxt is not None and len(nxt[2]) > 0:
+            # (only where the GPU step is long against the host's per-step work: at B = 100 the loop
+            # is host-bound and the extra call costs 15 %, profiles/r02_producer_bench.jsonl)
+            if plan_ahead and fused and nxt is not None and len(nxt[2]) >= 4096:
                 dn = nxt[3]
                 model.prefetch_plan(dn['times'], dn['time_ptr'], dn['X'], dn['obs_idx'], delta_t, T,
                                     dn['start_X'], dn['n_obs_ot'])
