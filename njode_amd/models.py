@@ -298,6 +298,7 @@ class NJODE(torch.nn.Module):
         self._step_counter = 0
 
         self._flat = None
+        self._flat_checks = 0
         self._flat_grad = None
         self._param_slices = None
         self._flat_params = None
@@ -316,6 +317,12 @@ class NJODE(torch.nn.Module):
         inc = (self.weight - 0.5)
         self.weight = 0.5 + inc * self.weight_decay
         return self.weight
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda() / .float() move the parameters: the flat vector is rebuilt on next use."""
+        out = super()._apply(fn, *args, **kwargs)
+        self._flat_checks = 63          # next _ensure_flat walks all parameters
+        return out
 
     # -- flat parameter storage -----------------------------------------------------------
     def _flat_slots(self):
@@ -339,6 +346,17 @@ class NJODE(torch.nn.Module):
     def _ensure_flat(self):
         """Make every parameter a view of one flat vector laid out as the C ABI expects
         (state_dict order; bias slots always present)."""
+        # fast path (the hot loop calls this four times per step): first and last parameter still
+        # sit where they were put; the full walk below runs every 64th call and after _apply()
+        if self._flat is not None and self._flat_params:
+            self._flat_checks += 1
+            if self._flat_checks & 63:
+                base = self._flat.data_ptr()
+                (o0, _, _), (o1, _, _) = self._param_slices[0], self._param_slices[-1]
+                p0, p1 = self._flat_params[0], self._flat_params[-1]
+                if (p0.data_ptr() == base + 4 * o0 and p1.data_ptr() == base + 4 * o1
+                        and p0.dtype == torch.float32):
+                    return
         slots = self._flat_slots()
         dev = slots[0][0].device
         total = sum(n for _, n, _ in slots)
