@@ -110,6 +110,9 @@ struct KArgs {
   // ... (masked models, njode_mfma_lock4.h) hidden activations of the ODE network at every step:
   // [K][tiles of 16 paths][4 waves][2 layers x 4 registers][64 lanes]
   float* lact;
+  // ... and of the three network evaluations of every jump (readout before, encoder, readout
+  // after): [row][4 waves][3 evaluations][2 layers][4 registers][4 lane groups]
+  float* jact;
   float* loss_terms;
   float* slab;
   float* trash;  // [64 * max(H, D)] scratch target for the stores of inactive lanes

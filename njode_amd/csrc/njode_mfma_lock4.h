@@ -335,6 +335,13 @@ NJ_DEV void q4_ode_keep(const KArgs& a, unsigned long long gid, int k, int g, in
   }
 }
 
+// Stored hidden activations of the three evaluations of a jump (readout before = 0, encoder = 1,
+// readout after = 2): per observation row and wave 3 x 2 x 4 registers x 4 lane groups
+constexpr int Q4_JACT_FLOATS = 3 * 2 * 4 * 4;   // = 96 per row and wave
+NJ_DEV float* q4_jact_ptr(float* jact, int row, int w, int set, int g) {
+  return jact + (((size_t)row * 4 + w) * 3 + set) * 32 + g;
+}
+
 // forward of one network: b0 (all units) -> this wave's output tile.  Two exchanges.
 template <class S, int ACT, bool DROP, class FP>
 NJ_DEV f32x4 q4_net_fwd(FP& F, lfp XA, lfp XB, const float (&b0)[S::Q0], uint32_t k1, uint32_t k2,
@@ -461,13 +468,28 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   for (int r = 0; r < 4; ++r) uo[r] = 16 * w + 4 * r + g;
 
   // readout of the state whose tanh is in image `TH` rows [0, H): this wave's tile of y
-  auto readout = [&](lfp TH, const float (&hq)[4], uint32_t tkey, uint32_t net, float (&y)[4]) {
-    float b0d[DS::Q0];
+  // store the own hidden activations of a jump evaluation for the sweep (set < 0: not a jump)
+  auto keep_acts = [&](int set, int row, bool on, const float (&a1l)[4], const float (&a2l)[4]) {
+    if (set < 0 || !SAVE) return;
+    float* p = on ? q4_jact_ptr(a.jact, row, w, set, g) : trash;
+    const int st4 = on ? 4 : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r * st4] = a1l[r];
+      p[(4 + r) * st4] = a2l[r];
+    }
+  };
+  // readout of the state whose tanh is in image `TH` rows [0, H): this wave's tile of y
+  auto readout = [&](lfp TH, const float (&hq)[4], uint32_t tkey, uint32_t net, float (&y)[4], int set,
+                     int row, bool on) {
+    float b0d[DS::Q0], a1l[4], a2l[4];
     q4_input<H, DS::Q0>(TH, b0d, g, c);
     q4_gathered();
     uint32_t k1, k2;
     q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
-    const f32x4 out = q4_net_fwd<DS, C::ACT, DROP>(Fd, XA, XB, b0d, k1, k2, a.dc.inv_keep, g, c, w);
+    const f32x4 out = q4_net_fwd_acts<DS, C::ACT, DROP>(Fd, XA, XB, b0d, k1, k2, a.dc.inv_keep, g, c, w,
+                                                        a1l, a2l);
+    keep_acts(set, row, on, a1l, a2l);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = out[r];
@@ -476,13 +498,15 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
     }
   };
   // encoder of [tanh(xin), mask] staged in EI: this wave's tile of the new state
-  auto encode = [&](const float (&xin)[4], uint32_t tkey, float (&hq)[4]) {
-    float b0e[ES::Q0];
+  auto encode = [&](const float (&xin)[4], uint32_t tkey, float (&hq)[4], int set, int row, bool on) {
+    float b0e[ES::Q0], a1l[4], a2l[4];
     q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
     q4_gathered();
     uint32_t k1, k2;
     q4_row_keep<DROP>(a, gid, tkey, NET_ENC, g, w, k1, k2);
-    const f32x4 out = q4_net_fwd<ES, C::ACT, DROP>(Fe, XA, XB, b0e, k1, k2, a.dc.inv_keep, g, c, w);
+    const f32x4 out = q4_net_fwd_acts<ES, C::ACT, DROP>(Fe, XA, XB, b0e, k1, k2, a.dc.inv_keep, g, c, w,
+                                                        a1l, a2l);
+    keep_acts(set, row, on, a1l, a2l);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = out[r];
@@ -503,7 +527,7 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   if constexpr (C::MASKED) q4_put_n<D>(EI, D, zero4, g, c, w);
   q4_put_n<D>(IN, H, txo, g, c, w);
   block_lds_barrier();
-  encode(xs, TKEY_START, h);
+  encode(xs, TKEY_START, h, -1, 0, false);
 #pragma unroll
   for (int r = 0; r < 4; ++r) th[r] = tanh_f(h[r]);
   q4_put_n<H>(IN, 0, th, g, c, w);
@@ -571,7 +595,7 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
             *dst = h[r];
           }
         }
-        readout(IN, h, (uint32_t)k, NET_DEC_BJ, ybj);
+        readout(IN, h, (uint32_t)k, NET_DEC_BJ, ybj, 0, r_, has);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           x[r] = uo[r] < D ? xraw[r] : 0.0f;
@@ -587,12 +611,12 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
         q4_put_n<D>(EI, 0, txin, g, c, w);
         if constexpr (C::MASKED) q4_put_n<D>(EI, D, m, g, c, w);
         block_lds_barrier();
-        encode(xin, (uint32_t)k, hn);
+        encode(xin, (uint32_t)k, hn, 1, r_, has);
 #pragma unroll
         for (int r = 0; r < 4; ++r) thn[r] = tanh_f(hn[r]);
         q4_put_n<H>(HN, 0, thn, g, c, w);
         block_lds_barrier();
-        readout(HN, hn, (uint32_t)k, NET_DEC, yn);
+        readout(HN, hn, (uint32_t)k, NET_DEC, yn, 2, r_, has);
         if (LOSS) {   // compute_loss (models.py:76-110) of this row, reduced over all units
           float sa = 0.0f, sb = 0.0f;
 #pragma unroll
@@ -714,18 +738,21 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   constexpr int T0X = H / 16, NB1 = 2;
   static_assert(M::MTB1 - T0X <= 4 && M::MTH <= 4, "one x tile and one h tile per wave");
   static_assert((D + 15) / 16 <= 4 && DS::MTI <= 4, "one input-gradient tile per wave for the row networks");
-  __shared__ __attribute__((aligned(16))) float lds_raw[L::ADJ_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_raw[L::IMAGES];
   lfp XA = (lfp)lds_raw, XB = XA + XFLOATS, XD = XB + XFLOATS, HN = XD + XFLOATS, IN = HN + XFLOATS,
       EI = IN + L::IN_FL, LX = EI + L::IN_FL, LR = LX + L::IN_FL;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < L::IMAGES; i += 256) lds_raw[i] = 0.0f;
+  // every evaluation's hidden activations come from the forward (lact: Euler steps, jact: the
+  // three evaluations of a jump), so the sweep only holds the transposed-product fragments:
+  // 50 + 37 + 37 registers
   Q4AdjStep<OS, NB1> Fo;
-  Q4AdjLds<ES> Fe;
-  Q4AdjReg<DS, 1> Fd;
+  Q4AdjStep<ES, 1> Fe;
+  Q4AdjStep<DS, 1> Fd;
   Fo.load(a.frag, w, lane, T0X);
-  Fe.load((lfp)lds_raw + L::IMAGES + w * Q4AdjLds<ES>::NVEC * 64, a.frag_enc, w, lane);
-  Fd.load(a.frag_dec, w, lane);
+  Fe.load(a.frag_enc, w, lane, 0);
+  Fd.load(a.frag_dec, w, lane, 0);
   __syncthreads();
 
   const int b0i = blockIdx.x * 16 + c;
@@ -777,36 +804,25 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
     q4_put_n<D>(IN, H, tx, g, c, w);
   };
 
-  // adjoint of y = readout(hq) w.r.t. hq: own tile of dh from the own tile of dy
-  auto dec_adj = [&](const float (&hq)[4], const float (&dy)[4], uint32_t tkey, uint32_t net, float (&dh)[4]) {
-    float thq[4], b0d[DS::Q0], a1l[4], a2l[4], dl[4], av[DS::Q1], dq[DS::QO], dv[DS::QW];
+  // adjoint of y = readout(hq) w.r.t. hq: own tile of dh from the own tile of dy; a1l / a2l: the
+  // evaluation's own hidden activations as the forward stored them
+  auto dec_adj = [&](const float (&hq)[4], const float (&dy)[4], const float (&a1l)[4],
+                     const float (&a2l)[4], float (&dh)[4]) {
+    float thq[4], dl[4], dq[DS::QO], dv[DS::QW];
 #pragma unroll
     for (int r = 0; r < 4; ++r) thq[r] = tanh_f(hq[r]);
-    q4_put_n<H>(HN, 0, thq, g, c, w);
     q4_put(XD, dy, g, c, w);
     block_lds_barrier();
-    q4_input<H, DS::Q0>(HN, b0d, g, c);
-    q4_gathered();
-    uint32_t k1, k2;
-    q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
-    Fd.begin();
-    f32x4 acc = q4_dot<DS::Q0>([&](int q) { return Fd.a1(q); }, b0d);
-    q4_hidden<DS::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
-    q4_put(XA, a1l, g, c, w);
-    block_lds_barrier();
-    split_get<DS::Q1>(XA, av, g, c);
     split_get<DS::QO>(XD, dq, g, c);
     q4_gathered();
-    acc = q4_dot<DS::Q1>([&](int q) { return Fd.a2(q); }, av);
-    q4_hidden<DS::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
-    acc = q4_dot<DS::QO>([&](int q) { return Fd.b3(q); }, dq);
-    q4_delta<DS::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
+    f32x4 acc = q4_dot<DS::QO>([&](int q) { return Fd.b3(q); }, dq);
+    q4_delta_stored<DS::W, C::ACT, DROP>(acc, a2l, dl, a.dc.inv_keep, a.keep, g, w);
     q4_put(XB, dl, g, c, w);
     block_lds_barrier();
     split_get<DS::QW>(XB, dv, g, c);
     q4_gathered();
     acc = q4_dot<DS::QW>([&](int q) { return Fd.b2(q); }, dv);
-    q4_delta<DS::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
+    q4_delta_stored<DS::W, C::ACT, DROP>(acc, a1l, dl, a.dc.inv_keep, a.keep, g, w);
     q4_put(XA, dl, g, c, w);
     block_lds_barrier();
     split_get<DS::QW>(XA, dv, g, c);
@@ -955,6 +971,16 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
       if (__any(has)) {
         const int r_ = has ? src : 0;
         float hn[4], hp[4], x[4], m[4], y[4], ybj[4], dy[4], dybj[4], dh[4], lam_hn[4], lam_new[4];
+        float ja[3][2][4];   // hidden activations of the jump's three evaluations (forward's)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const float* p = q4_jact_ptr(a.jact, r_, w, e, g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            ja[e][0][r] = p[r * 4];
+            ja[e][1][r] = p[(4 + r) * 4];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           // the state after the jump = the state before step k: in registers unless k == K
@@ -1028,7 +1054,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
           float* dst = (has && uo[r] < DO) ? a.g_y + (size_t)r_ * DO + uo[r] : trash;
           *dst = dy[r];
         }
-        dec_adj(hn, dy, (uint32_t)k, NET_DEC, dh);
+        dec_adj(hn, dy, ja[2][0], ja[2][1], dh);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           lam_hn[r] = lam[r] + dh[r];
@@ -1037,38 +1063,21 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
         }
         if constexpr (C::MASKED) {
           // h_new = encoder(x_in, M), x_in = X M + (1 - M) y_bj
-          float xin[4], txin[4], b0e[ES::Q0], a1l[4], a2l[4], dl[4], av[ES::Q1], dq[ES::QO], dv[ES::QW];
+          float txin[4], dl[4], dq[ES::QO], dv[ES::QW];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            xin[r] = x[r] * m[r] + (1.0f - m[r]) * ybj[r];
-            txin[r] = tanh_f(xin[r]);
-          }
-          q4_put_n<D>(EI, 0, txin, g, c, w);
-          q4_put_n<D>(EI, D, m, g, c, w);
+          for (int r = 0; r < 4; ++r) txin[r] = tanh_f(x[r] * m[r] + (1.0f - m[r]) * ybj[r]);
           q4_put(XD, lam_hn, g, c, w);
           block_lds_barrier();
-          q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
-          q4_gathered();
-          uint32_t k1, k2;
-          q4_row_keep<DROP>(a, gid, (uint32_t)k, NET_ENC, g, w, k1, k2);
-          Fe.begin();
-          f32x4 acc = q4_dot<ES::Q0>([&](int q) { return Fe.a1(q); }, b0e);
-          q4_hidden<ES::W, C::ACT, DROP>(acc, a1l, k1, a.dc.inv_keep, g, w);
-          q4_put(XA, a1l, g, c, w);
-          block_lds_barrier();
-          split_get<ES::Q1>(XA, av, g, c);
           split_get<ES::QO>(XD, dq, g, c);
           q4_gathered();
-          acc = q4_dot<ES::Q1>([&](int q) { return Fe.a2(q); }, av);
-          q4_hidden<ES::W, C::ACT, DROP>(acc, a2l, k2, a.dc.inv_keep, g, w);
-          acc = q4_dot<ES::QO>([&](int q) { return Fe.b3(q); }, dq);
-          q4_delta<ES::W, C::ACT, DROP>(acc, a2l, dl, k2, a.dc.inv_keep, a.keep, g, w);
+          f32x4 acc = q4_dot<ES::QO>([&](int q) { return Fe.b3(q); }, dq);
+          q4_delta_stored<ES::W, C::ACT, DROP>(acc, ja[1][1], dl, a.dc.inv_keep, a.keep, g, w);
           q4_put(XB, dl, g, c, w);
           block_lds_barrier();
           split_get<ES::QW>(XB, dv, g, c);
           q4_gathered();
           acc = q4_dot<ES::QW>([&](int q) { return Fe.b2(q); }, dv);
-          q4_delta<ES::W, C::ACT, DROP>(acc, a1l, dl, k1, a.dc.inv_keep, a.keep, g, w);
+          q4_delta_stored<ES::W, C::ACT, DROP>(acc, ja[1][0], dl, a.dc.inv_keep, a.keep, g, w);
           q4_put(XA, dl, g, c, w);
           block_lds_barrier();
           split_get<ES::QW>(XA, dv, g, c);
@@ -1088,7 +1097,7 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
           float* dst = (has && uo[r] < DO) ? a.g_ybj + (size_t)r_ * DO + uo[r] : trash;
           *dst = dybj[r];
         }
-        dec_adj(hp, dybj, (uint32_t)k, NET_DEC_BJ, lam_new);
+        dec_adj(hp, dybj, ja[0][0], ja[0][1], lam_new);
         // commit for the paths that have this observation
 #pragma unroll
         for (int r = 0; r < 4; ++r) lam[r] = has ? lam_new[r] : lam[r];
