@@ -11,11 +11,19 @@ step over all 20 000 paths of this rank as ONE batch:
     + Adam(lr 1e-3, weight_decay 5e-4) on the flat parameter vector.
 Inputs (start_X, X, obs_idx, n_obs_ot) are resident in HBM before the timed region.
 N > 1: every rank holds its own 20 000 paths (weak scaling; --paths-per-gpu), or, with
---global-paths G, the ranks share G paths (strong scaling, G / N each); the loss is
-normalised by the global batch, one gradient all-reduce per step.
+--global-paths G, the ranks share G paths (strong scaling, G / N each; BASELINE config 4 =
+--gpus 8 --global-paths 1000000); the loss is normalised by the global batch, one gradient
+all-reduce per step.  The global dataset is a sequence of 20 000-path chunks, chunk c drawn
+with seed c, and rank r owns a contiguous slice of it -- so an N-rank run and a 1-rank run
+over the same number of paths see the same data (and, dropout being keyed by the global
+path id, the same masks).
 
-Launch:  python bench.py --gpus 1 --steps K --warmup W
-         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Launch:  python bench.py --gpus N --steps K --warmup W
+  * N = 1, or under a launcher (WORLD_SIZE set: `python -m torch.distributed.run
+    --nproc-per-node N ... bench.py --gpus N ...`): this process is a rank.
+  * N > 1 without a launcher: this process only SPAWNS the N ranks (torch.distributed.run as a
+    child process, started before anything here touches the GPU), relays rank 0's line and
+    exits with the children's code.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -23,6 +31,8 @@ import contextlib
 import copy
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -49,6 +59,29 @@ def make_batch(n_paths, seed):
     hp = copy.deepcopy(data_utils.hyperparam_default)
     hp['nb_paths'] = n_paths
     paths, obs, nb_obs, meta = data_utils.create_dataset('BlackScholes', hp, seed=seed)
+    return data_utils.collate_arrays(paths, obs, nb_obs, meta['dt']), meta
+
+
+CHUNK = 20000   # paths per chunk of the global dataset (chunk c is drawn with seed c)
+
+
+def make_global_slice(lo, hi):
+    """Paths [lo, hi) of the global synthetic dataset, collated as ONE batch.  The dataset is a
+    sequence of CHUNK-path Black-Scholes blocks, block c = create_dataset(seed=c) (so the default
+    N = 1 workload is exactly the seed-0 20 000-path dataset), which makes the data a function of
+    the global path index only: however the paths are sharded over ranks, their union is the
+    same dataset."""
+    from njode_amd import data_utils
+    hp = copy.deepcopy(data_utils.hyperparam_default)
+    hp['nb_paths'] = CHUNK
+    parts, meta = [], None
+    for c in range(lo // CHUNK, (max(hi, lo + 1) - 1) // CHUNK + 1):
+        paths, obs, nb_obs, meta = data_utils.create_dataset('BlackScholes', hp, seed=c)
+        a, b = max(lo, c * CHUNK) - c * CHUNK, min(hi, (c + 1) * CHUNK) - c * CHUNK
+        parts.append((paths[a:b], obs[a:b], nb_obs[a:b]))
+    paths = np.concatenate([p[0] for p in parts])
+    obs = np.concatenate([p[1] for p in parts])
+    nb_obs = np.concatenate([p[2] for p in parts])
     return data_utils.collate_arrays(paths, obs, nb_obs, meta['dt']), meta
 
 
@@ -168,12 +201,12 @@ def small_batch_ms(model, opt, dev, dt, T, sizes=(100, 200), steps=30, prefetch=
 
         def one():
             if prefetch:
-                model.prefetch_plan(*args)
+                model.prefetch_plan(*args, need_hT=False)
             model.loss_and_grad(*args)
             opt.step()
 
         if prefetch:
-            model.prefetch_plan(*args)
+            model.prefetch_plan(*args, need_hT=False)
         for _ in range(5):
             one()
         torch.cuda.synchronize()
@@ -184,6 +217,59 @@ def small_batch_ms(model, opt, dev, dt, T, sizes=(100, 200), steps=30, prefetch=
         out[bsz] = 1e3 * (time.perf_counter() - t0) / steps
         model._plans.clear()
     return out
+
+
+def autograd_route_ms(dev, dt, T, step_args, dropout, steps):
+    """The literal call sequence of the reference's training loop (train.py:492-523) on the same
+    resident batch: optimizer.zero_grad(); hT, loss = model(...); loss.backward();
+    torch.optim.Adam(lr 1e-3, weight_decay 5e-4).step() -- the autograd bridge, hT included (the
+    fused step skips the per-path tail evolve nobody reads), no plan prefetch, no fused Adam.
+    A fresh model; an extra outside the timed region of `value`."""
+    from njode_amd import models
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        m = models.NJODE(**model_cfg(dropout)).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0005)
+
+    def one():
+        opt.zero_grad()
+        hT, loss = m(*step_args, return_path=False, get_loss=True)
+        loss.backward()
+        opt.step()
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relay their
+    output (rank 0 prints the JSON line) and return their exit code.  This parent never touches
+    the GPU and never replaces itself."""
+    share = os.environ.get('NJODE_BENCH_SHARE_GPU') == '1'
+    n_dev = torch.cuda.device_count()            # (does not initialise the GPU)
+    if n_dev < n and not share:
+        print('bench.py: --gpus {} but this node has {} GPU(s)'.format(n, n_dev), file=sys.stderr)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -199,23 +285,34 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-small-batch', action='store_true')
+    ap.add_argument('--no-autograd-route', action='store_true')
+    ap.add_argument('--dump-params', default='',
+                    help='rank 0 saves the flat parameter vector after the timed steps (.npy)')
     ap.add_argument('--no-plan-prefetch', action='store_true',
                     help='build every step\'s plan in line instead of one step ahead')
     args = ap.parse_args()
 
+    launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if args.gpus > 1 and not launched:
+        # no launcher: spawn the ranks.  Nothing in this process has touched the GPU
+        # (importing torch and counting devices does not initialise it).
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1
-    if args.gpus != world and distributed:
+    if args.gpus != world:
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
-    if args.gpus > 1 and not distributed:
-        raise SystemExit('launch N > 1 with torch.distributed.run (one rank per GPU)')
     # NJODE_BENCH_SHARE_GPU=1 (self-test of the N > 1 code path on a one-GPU box): ranks share
     # device 0 and the collective runs over gloo; never set by the driver
     share = os.environ.get('NJODE_BENCH_SHARE_GPU') == '1'
+    n_dev = torch.cuda.device_count()
     if share:
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % max(n_dev, 1)
+    elif local_rank >= n_dev:
+        raise SystemExit('rank {} needs cuda:{} but this node has {} GPU(s) (one rank per GPU; '
+                         'NJODE_BENCH_SHARE_GPU=1 runs the ranks on one device over gloo as a '
+                         'self-test)'.format(rank, local_rank, n_dev))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     backend = None
@@ -230,13 +327,10 @@ def main():
     from njode_amd import _lib, models, parallel
 
     strong = args.global_paths > 0
-    if strong:
-        lo, hi = parallel.shard_range(args.global_paths, world, rank)
-        B, path_offset, global_batch = hi - lo, lo, args.global_paths
-    else:
-        B = args.paths_per_gpu
-        path_offset, global_batch = B * rank, B * world
-    b, meta = make_batch(B, seed=rank)
+    global_batch = args.global_paths if strong else args.paths_per_gpu * world
+    lo, hi = parallel.shard_range(global_batch, world, rank)
+    B, path_offset = hi - lo, lo
+    b, meta = make_global_slice(lo, hi)
     dt, T = meta['dt'], meta['maturity']
     torch.manual_seed(0)                       # identical init on every rank
     with contextlib.redirect_stdout(sys.stderr):   # the ctor prints like the reference's does
@@ -259,13 +353,13 @@ def main():
 
     def step():
         if prefetch:
-            model.prefetch_plan(*step_args)
+            model.prefetch_plan(*step_args, need_hT=False)
         _, loss = model.loss_and_grad(*step_args)
         opt.step()
         return loss
 
     if prefetch:
-        model.prefetch_plan(*step_args)   # the first step's own plan
+        model.prefetch_plan(*step_args, need_hT=False)   # the first step's own plan
 
     def sync():
         torch.cuda.synchronize()
@@ -275,7 +369,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    timing = not args.no_kernel_timing
+    timing = not args.no_kernel_timing and world == 1   # per-kernel times / roofline: N = 1 only
     sync()
     # HIP events inside the timed region: around the DOMINANT kernel only (the ODE backward) --
     # bracketing all six hot kernels costs ~3.5 % of the step.  The other kernels' times come
@@ -290,6 +384,7 @@ def main():
     elapsed_local = time.perf_counter() - t0
     opt.time_allreduce = False
     allreduce_ms = opt.allreduce_ms()
+    flat_after = model.flat_parameters().detach().clone()   # parameters after warmup + K steps
     kern, kern_timed = {}, {}
     if timing:
         _lib.profile_enable(False)
@@ -309,7 +404,20 @@ def main():
         per_rank = [float(x) for x in gathered]
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t)
-    final_loss = float(loss)
+    # the ranks' losses are partial sums over their shards (global denominator): add them up;
+    # and every rank must hold the same parameters after the same all-reduced steps
+    lsum = loss.detach().reshape(1).to(torch.float64).clone()
+    flat = flat_after
+    identical = True
+    if distributed:
+        torch.distributed.all_reduce(lsum)
+        pmax, pmin = flat.clone(), flat.clone()
+        torch.distributed.all_reduce(pmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(pmin, op=torch.distributed.ReduceOp.MIN)
+        identical = bool(torch.equal(pmax, pmin))
+    final_loss = float(lsum)
+    if args.dump_params and rank == 0:
+        np.save(args.dump_params, flat.cpu().numpy())
 
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
@@ -334,6 +442,7 @@ def main():
             'plan_prefetch': bool(prefetch),
         }
         if distributed:
+            out['params_identical_across_ranks'] = identical
             out['rccl_world'] = torch.distributed.get_world_size()
             out['collective_backend'] = backend + (' (RCCL)' if backend == 'nccl' else '')
             out['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 5)
@@ -408,6 +517,11 @@ def main():
             out['b200_ms'] = round(sb[200], 4)
             out['b100_paths_per_s'] = round(100 / (sb[100] * 1e-3), 1)
             out['b200_paths_per_s'] = round(200 / (sb[200] * 1e-3), 1)
+        if world == 1 and not args.no_autograd_route:
+            model._plans.clear()
+            out['autograd_route_ms'] = round(autograd_route_ms(dev, dt, T, step_args, args.dropout,
+                                                               args.steps), 4)
+            out['autograd_route_paths_per_s'] = round(B / (out['autograd_route_ms'] * 1e-3), 1)
         if world == 1 and not args.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):
                 out['cpu_baseline'] = cpu_baseline(dt, T)

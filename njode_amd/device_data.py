@@ -138,11 +138,25 @@ class DeviceDataset:
                 self.nb_obs.cpu().numpy().astype(np.int64))
 
     # -- batches -------------------------------------------------------------------------
-    def collate(self, idx=None, func_names=()):
+    def collate(self, idx=None, func_names=(), stream=None):
         """The batch ``custom_collate_fn`` builds for dataset rows ``idx`` (device int32
         tensor / array-like in batch order; None = the whole dataset), with ``X``,
         ``start_X``, ``obs_idx`` (int32) and ``n_obs_ot`` (int32) on the device and
-        ``times`` / ``time_ptr`` as numpy arrays."""
+        ``times`` / ``time_ptr`` as numpy arrays.
+
+        The per-time counts must reach the host before ``X`` can be sized, so the call waits for
+        its own first kernel.  ``stream``: run the collate there (a side stream) -- the wait then
+        covers the collate only, not the training step queued on the current stream, and the
+        returned dict carries ``'ready'``, an event the consumer's stream must wait for."""
+        if stream is not None:
+            cur = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(stream):
+                out = self.collate(idx, func_names)
+                out['ready'] = torch.cuda.Event()
+                out['ready'].record(stream)
+            for k in ('X', 'start_X', 'obs_idx', 'n_obs_ot'):
+                out[k].record_stream(cur)
+            return out
         L = _lib.lib()
         dev = self.device
         if idx is not None:
@@ -176,3 +190,64 @@ class DeviceDataset:
                                             _ptr(obs_idx) if n_obs else C.c_void_p(0), st))
         return {'times': times, 'time_ptr': time_ptr, 'obs_idx': obs_idx, 'start_X': start_X,
                 'n_obs_ot': n_obs_ot, 'X': X}
+
+    # -- a whole epoch's batches: one host round trip instead of one per batch -----------------
+    def prepare_batches(self, idx_list):
+        """Phase 1 of the collate (per-time observation counts) for MANY batches at once: the
+        count kernels of all batches are enqueued back to back, their results cross PCIe in ONE
+        copy and the host waits ONCE -- a training loop at the reference's batch sizes
+        (B = 100 / 200) is host-bound, and the per-batch wait for its own count kernel was the
+        largest item of its step.  ``idx_list``: dataset rows of each batch (array-likes on the
+        host, in batch order).  Returns one descriptor per batch for ``fill_batch``."""
+        L = _lib.lib()
+        dev = self.device
+        sizes = [len(ix) for ix in idx_list]
+        if not sizes or min(sizes) <= 0:
+            raise ValueError('empty batch')
+        flat = np.concatenate([np.asarray(ix, dtype=np.int32) for ix in idx_list])
+        idx_dev = torch.as_tensor(flat).to(dev)                       # one upload per epoch
+        n = len(sizes)
+        counts = torch.empty((n, self.n_steps), dtype=torch.int32, device=dev)
+        n_obs_ot = torch.empty(len(flat), dtype=torch.int32, device=dev)
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            for i in range(n):
+                lo, hi = int(offs[i]), int(offs[i + 1])
+                _lib.check(L.njode_collate_count(
+                    _ptr(self.observed_tm), _ptr(self.nb_obs), self.n_paths, self.n_steps,
+                    C.c_void_p(idx_dev.data_ptr() + 4 * lo), hi - lo,
+                    C.c_void_p(counts.data_ptr() + 4 * i * self.n_steps),
+                    C.c_void_p(n_obs_ot.data_ptr() + 4 * lo), st))
+            counts_host = counts.cpu().numpy()                        # one copy, one wait
+        out = []
+        for i in range(n):
+            lo, hi = int(offs[i]), int(offs[i + 1])
+            times, time_ptr = times_from_counts(counts_host[i], self.metadata['dt'])
+            out.append({'times': times, 'time_ptr': time_ptr, 'idx': idx_dev[lo:hi],
+                        'counts': counts[i], 'n_obs_ot': n_obs_ot[lo:hi], 'B': hi - lo})
+        return out
+
+    def fill_batch(self, prep, func_names=()):
+        """Phase 2 for one descriptor of ``prepare_batches``: two kernel launches, no host
+        wait.  Same batch, bit for bit, as ``collate`` builds."""
+        L = _lib.lib()
+        dev = self.device
+        B = prep['B']
+        powers = parse_powers(func_names)
+        width = self.dim * (1 + len(powers))
+        pw = (C.c_int32 * max(len(powers), 1))(*powers)
+        n_obs = int(prep['time_ptr'][-1])
+        start_X = torch.empty((B, width), dtype=torch.float32, device=dev)
+        X = torch.empty((n_obs, width), dtype=torch.float32, device=dev)
+        obs_idx = torch.empty(n_obs, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.njode_collate_fill(_ptr(self.paths_tm), _ptr(self.observed_tm),
+                                            self.n_paths, self.dim, self.n_steps,
+                                            _ptr(prep['idx']), B, _ptr(prep['counts']), pw,
+                                            len(powers), _ptr(start_X),
+                                            _ptr(X) if n_obs else C.c_void_p(0),
+                                            _ptr(obs_idx) if n_obs else C.c_void_p(0),
+                                            _stream(dev)))
+        return {'times': prep['times'], 'time_ptr': prep['time_ptr'], 'obs_idx': obs_idx,
+                'start_X': start_X, 'n_obs_ot': prep['n_obs_ot'], 'X': X}

@@ -200,8 +200,12 @@ class _Call:
 
 class _Plan:
     """A plan built ahead by ``NJODE.prefetch_plan``; its buffer returns to the model's pool
-    when the last call that reads it is gone."""
-    __slots__ = ('buf', 'done', 'flags', 'sizes', 'keep', 'pool')
+    when the last call that reads it is gone.  It holds the ORIGINAL ``obs_idx`` / ``time_ptr``
+    objects of its batch (so their ids cannot be recycled for another batch while the plan is
+    queued) and the version counter ``obs_idx`` had: a call only takes a plan of the very same,
+    unmodified objects."""
+    __slots__ = ('buf', 'done', 'flags', 'sizes', 'keep', 'pool', 'obs_idx', 'time_ptr',
+                 'obs_version', 'taken')
 
     def __del__(self):
         pool, buf = getattr(self, 'pool', None), getattr(self, 'buf', None)
@@ -307,7 +311,8 @@ class NJODE(torch.nn.Module):
         self._ring = None
         self._ws_pool = []
         self._dims = None
-        self._plans = {}
+        self._plans = []
+        self._last_stream = None
         self._plan_pool = []
         self._plan_stream = None
 
@@ -343,12 +348,14 @@ class NJODE(torch.nn.Module):
             slots.append((getattr(g, 'bias_hh', None), H3, (H3,)))
         return slots
 
-    def _ensure_flat(self):
+    def _ensure_flat(self, full=False):
         """Make every parameter a view of one flat vector laid out as the C ABI expects
-        (state_dict order; bias slots always present)."""
-        # fast path (the hot loop calls this four times per step): first and last parameter still
-        # sit where they were put; the full walk below runs every 64th call and after _apply()
-        if self._flat is not None and self._flat_params:
+        (state_dict order; bias slots always present).  ``full``: walk all parameters (once per
+        library call, from ``_make_call``: a parameter re-pointed by ``p.data = ...`` or
+        ``load_state_dict(assign=True)`` is caught before the kernels read the flat vector)."""
+        # fast path (the hot loop calls this several times per step): first and last parameter
+        # still sit where they were put; the full walk below runs once per call and after _apply()
+        if self._flat is not None and self._flat_params and not full:
             self._flat_checks += 1
             if self._flat_checks & 63:
                 base = self._flat.data_ptr()
@@ -357,19 +364,18 @@ class NJODE(torch.nn.Module):
                 if (p0.data_ptr() == base + 4 * o0 and p1.data_ptr() == base + 4 * o1
                         and p0.dtype == torch.float32):
                     return
-        slots = self._flat_slots()
-        dev = slots[0][0].device
-        total = sum(n for _, n, _ in slots)
-        ok = (self._flat is not None and self._flat.device == dev
-              and self._flat.numel() == total)
-        if ok:
+        if self._flat is not None and self._flat_params:
             base = self._flat.data_ptr()
+            ok = True
             for (off, n, _), p in zip(self._param_slices, self._flat_params):
                 if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
                     ok = False
                     break
-        if ok:
-            return
+            if ok:
+                return
+        slots = self._flat_slots()
+        dev = slots[0][0].device
+        total = sum(n for _, n, _ in slots)
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         slices, params, off = [], [], 0
         for p, n, shape in slots:
@@ -447,7 +453,10 @@ class NJODE(torch.nn.Module):
             call.ws_slot = None
 
     def _make_call(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
-                   return_path, get_loss, until_T, M, save_bwd, plan_key=None, plan_only=False):
+                   return_path, get_loss, until_T, M, save_bwd, plan_key=None, plan_only=False,
+                   want_hT=True, plan=None):
+        """``plan_key`` = the caller's original ``(obs_idx, time_ptr)`` objects (looked up among
+        the prefetched plans by identity); ``plan`` = a handle returned by ``prefetch_plan``."""
         L = _lib.lib()
         dev = start_X.device
         if dev.type != 'cuda':
@@ -455,7 +464,7 @@ class NJODE(torch.nn.Module):
                 'njode_amd.NJODE runs on an MI355X only (inputs are on {}); there is no '
                 'CPU path. Move the model and the batch to a cuda device.'.format(dev))
         dims = self._get_dims()
-        self._ensure_flat()
+        self._ensure_flat(full=True)
         if self._flat.device != dev:
             raise RuntimeError('model parameters are on {} but the batch is on {}'.format(
                 self._flat.device, dev))
@@ -502,9 +511,8 @@ class NJODE(torch.nn.Module):
                  | _lib.C_SCHED_KNOWN | (_lib.C_SCHED_TAIL if sched.has_tail() else 0))
         if plan_only:   # prefetch_plan: the structs of the call, nothing allocated or counted
             return dims, cb, cs, flags, keep + [pinned], slot_i, (B, n_obs, nt, K)
-        plan = None
-        if plan_key is not None:
-            plan = self._take_plan(plan_key, flags, B, n_obs, nt, K)
+        if plan is not None or (plan_key is not None and self._plans):
+            plan = self._take_plan(plan, plan_key, flags, (B, n_obs, nt, K), want_hT)
         if plan is not None:
             cb.plan = plan.buf.data_ptr()
             flags |= _lib.C_PLAN_READY | (plan.flags & _lib.C_NEED_HT)
@@ -525,9 +533,10 @@ class NJODE(torch.nn.Module):
         call.keep = keep + [pinned]
         return call, sched, slot_i, B
 
-    def _run_forward(self, call, hT, loss, path_h, path_y, slot_i):
+    def _run_forward(self, call, hT, loss, path_h, path_y, slot_i, stream=None):
         L = _lib.lib()
-        stream = torch.cuda.current_stream()
+        if stream is None:
+            stream = torch.cuda.current_stream()
         rc = L.njode_forward_f32(
             ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(call.batch),
             ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
@@ -539,11 +548,12 @@ class NJODE(torch.nn.Module):
         self._ring.release_after(slot_i, stream)
         _lib.check(rc)
 
-    def _run_backward(self, call, grad_loss, grad_flat, loss=None):
+    def _run_backward(self, call, grad_loss, grad_flat, loss=None, stream=None):
         """``loss`` given: the fused step's backward, which may also produce the loss
         (``NJODE_C_LOSS_IN_BWD``, see ``loss_and_grad``)."""
         L = _lib.lib()
-        stream = torch.cuda.current_stream()
+        if stream is None:
+            stream = torch.cuda.current_stream()
         if call.ws_slot is None:
             raise RuntimeError(
                 'the workspace saved by this forward was already released: a second backward '
@@ -571,8 +581,11 @@ class NJODE(torch.nn.Module):
         schedule only, not on the parameters; the call that later receives the same batch
         (same ``obs_idx`` tensor and ``time_ptr`` array, in the order they were prefetched)
         picks it up and skips its own plan stage.  Call it for batch i+1 right before the
-        step on batch i.  ``need_hT``: the coming call returns hT (default: masked models)."""
-        need_hT = self.masked if need_hT is None else bool(need_hT)
+        step on batch i.  Returns a handle that may be passed to that call as ``plan=``
+        (otherwise the call finds it by the identity of ``obs_idx`` and ``time_ptr``).
+        ``need_hT``: the coming call returns hT.  Default True -- ``forward`` always does;
+        ``loss_and_grad`` of an unmasked model does not and simply ignores the tail order."""
+        need_hT = True if need_hT is None else bool(need_hT)
         dims, cb, cs, flags, keep, slot_i, (B, n_obs, nt, K) = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False, M,
             save_bwd=True, plan_only=True)
@@ -584,10 +597,9 @@ class NJODE(torch.nn.Module):
                                       ctypes.byref(need)))
         dev = start_X.device
         buf = None
-        for cand in self._plan_pool:
+        for i, cand in enumerate(self._plan_pool):
             if cand.device == dev and cand.numel() >= need.value:
-                buf = cand
-                self._plan_pool.remove(cand)
+                buf = self._plan_pool.pop(i)     # (list.remove would compare tensors by value)
                 break
         if buf is None:
             buf = torch.empty(int(need.value * 1.25) + 4096, dtype=torch.uint8, device=dev)
@@ -605,39 +617,48 @@ class NJODE(torch.nn.Module):
         plan = _Plan()
         plan.buf, plan.done, plan.flags, plan.sizes, plan.keep = buf, done, flags, (B, n_obs, nt, K), keep
         plan.pool = self._plan_pool
-        self._plans.setdefault(self._plan_key(obs_idx, time_ptr), []).append(plan)
+        plan.obs_idx, plan.time_ptr, plan.taken = obs_idx, time_ptr, False
+        plan.obs_version = getattr(obs_idx, '_version', 0)
+        self._plans.append(plan)
         # plans nobody picks up (a prefetched batch that is then never stepped on) must not pile
         # up: keep the four newest
-        while sum(len(q) for q in self._plans.values()) > 4:
-            k0 = next(iter(self._plans))
-            self._plans[k0].pop(0)
-            if not self._plans[k0]:
-                del self._plans[k0]
-
-    @staticmethod
-    def _plan_key(obs_idx, time_ptr):
-        return (id(obs_idx), id(time_ptr))
-
-    def _take_plan(self, key, flags, B, n_obs, nt, K):
-        """Oldest prefetched plan of this batch, if it was made for this kind of call."""
-        q = self._plans.get(key)
-        if not q:
-            return None
-        plan = q[0]
-        want = flags & ~(_lib.C_LOSS_IN_BWD | _lib.C_PLAN_READY)
-        if plan.sizes != (B, n_obs, nt, K) or (plan.flags & ~_lib.C_NEED_HT) != want:
-            return None
-        q.pop(0)
-        if not q:
-            del self._plans[key]
+        while len(self._plans) > 4:
+            self._plans.pop(0)
         return plan
+
+    def _take_plan(self, plan, key, flags, sizes, want_hT):
+        """The prefetched plan of this call, or None (the call then builds its own in line).
+        ``plan`` given: the handle ``prefetch_plan`` returned; else the oldest queued plan whose
+        ``obs_idx`` / ``time_ptr`` ARE (identity) the caller's objects.  A plan that was made for
+        a different kind of call (sizes, flags, no tail order although hT is wanted) or whose
+        ``obs_idx`` was modified in place since is dropped, never used and never left to block
+        the plans queued behind it."""
+        if plan is None:
+            obs_idx, time_ptr = key
+            for cand in self._plans:
+                if cand.obs_idx is obs_idx and cand.time_ptr is time_ptr:
+                    plan = cand
+                    break
+            if plan is None:
+                return None
+        if plan.taken:
+            raise RuntimeError('this prefetched plan was already consumed by an earlier call')
+        if plan in self._plans:
+            self._plans.remove(plan)
+        plan.taken = True
+        want = flags & ~(_lib.C_LOSS_IN_BWD | _lib.C_PLAN_READY)
+        ok = (plan.sizes == sizes and (plan.flags & ~_lib.C_NEED_HT) == want
+              and getattr(plan.obs_idx, '_version', 0) == plan.obs_version
+              and (not want_hT or self.masked or (plan.flags & _lib.C_NEED_HT)))
+        return plan if ok else None
 
     # -- forward -------------------------------------------------------------------------
     def forward(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
-                return_path=False, get_loss=True, until_T=False, M=None):
+                return_path=False, get_loss=True, until_T=False, M=None, plan=None):
         """Same contract as the reference's ``NJODE.forward`` (``models.py:379-518``):
         returns ``(hT, loss)`` or ``(hT, loss, path_t, path_h, path_y)``; ``loss`` is
-        the Python int 0 when ``get_loss=False``."""
+        the Python int 0 when ``get_loss=False``.  ``plan`` (optional, not in the reference):
+        the handle ``prefetch_plan`` returned for this batch."""
         want_grad = (torch.is_grad_enabled() and get_loss
                      and any(p.requires_grad for p in self.parameters()))
         if self.torch_library_op and not return_path:
@@ -646,7 +667,7 @@ class NJODE(torch.nn.Module):
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, return_path,
             get_loss, until_T, M, save_bwd=want_grad,
-            plan_key=self._plan_key(obs_idx, time_ptr) if self._plans else None)
+            plan_key=(obs_idx, time_ptr), want_hT=True, plan=plan)
         dev = start_X.device
         hT = torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
         loss = torch.zeros(1, dtype=torch.float32, device=dev) if get_loss else None
@@ -692,7 +713,7 @@ class NJODE(torch.nn.Module):
 
     # -- fused training step (no autograd graph) ------------------------------------------
     def loss_and_grad(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
-                      M=None):
+                      M=None, plan=None):
         """Forward + exact gradient in two library calls, no autograd bookkeeping:
         returns ``(None, loss)`` (device loss tensor; hT is not computed -- it would
         cost a per-path tail evolve nobody reads) and fills ``flat_grad()`` (whose
@@ -703,7 +724,7 @@ class NJODE(torch.nn.Module):
         grad = self.flat_grad()
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
-            M, save_bwd=True, plan_key=self._plan_key(obs_idx, time_ptr) if self._plans else None)
+            M, save_bwd=True, plan_key=(obs_idx, time_ptr), want_hT=self.masked, plan=plan)
         dev = start_X.device
         loss = torch.empty(1, dtype=torch.float32, device=dev)   # (always written: sum of the terms)
         # hT is only skipped on the segment plan (unmasked): there it would cost an extra
@@ -711,11 +732,13 @@ class NJODE(torch.nn.Module):
         hT = (torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
               if self.masked else None)
         call.flags |= _lib.C_LOSS_IN_BWD
+        stream = torch.cuda.current_stream(dev)      # (one lookup per step: ~7 us each)
+        self._last_stream = stream
         try:
-            self._run_forward(call, hT, loss, None, None, slot_i)
+            self._run_forward(call, hT, loss, None, None, slot_i, stream)
             if self._ones is None or self._ones.device != dev:
                 self._ones = torch.ones(1, dtype=torch.float32, device=dev)
-            self._run_backward(call, self._ones, grad, loss=loss)
+            self._run_backward(call, self._ones, grad, loss=loss, stream=stream)
         finally:
             self._release_ws(call)
         return hT, loss.reshape(())

@@ -20,7 +20,13 @@ Operator schema::
 * ``times`` (float64) / ``time_ptr`` (int64): CPU tensors, the reference's host-side arrays;
 * ``model_id``: handle of the ``NJODE`` instance (shapes, options and the workspace pool live
   there; the registry holds weak references);
-* ``call_id`` (CPU int64 scalar): handle of the saved forward, consumed by the backward.
+* ``call_id`` (CPU int64 scalar): handle of the saved forward, consumed by the backward (and
+  released with the autograd node if no backward ever runs).
+
+Hidden state: a training-mode call advances the model's dropout step counter (the seed of the
+next call's masks) although the schema declares no mutated argument -- two calls with equal
+arguments are NOT interchangeable, so do not let a graph pass deduplicate or reorder them
+(the op is opaque to ``torch.compile``, which keeps the calls in program order).
 """
 import weakref
 from typing import List, Optional, Tuple
@@ -73,10 +79,22 @@ def _(params, start_X, X, obs_idx, n_obs_ot, M, times, time_ptr, delta_t, T, mod
     return hT, start_X.new_empty((1,), dtype=torch.float32), torch.empty((), dtype=torch.int64)
 
 
+def _drop_call(call_id):
+    """The autograd node of a saving forward is gone (back-propagated, or its graph dropped
+    without a backward, e.g. a validation loss computed without no_grad): release the saved
+    call, which returns its workspace to the model's pool."""
+    call = _CALLS.pop(call_id, None)
+    if call is not None and call.ws_slot is not None:
+        call.ws_slot[1] = False
+        call.ws_slot = None
+
+
 def _setup_context(ctx, inputs, output):
     ctx.model_id = inputs[10]
     ctx.n_params = len(inputs[0])
     ctx.call_id = int(output[2])
+    if ctx.call_id:
+        weakref.finalize(ctx, _drop_call, ctx.call_id)
 
 
 def _backward(ctx, grad_hT, grad_loss, grad_id):

@@ -161,18 +161,35 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                 d = dict(times=None, time_ptr=None, X=None, obs_idx=None, start_X=None,
                          n_obs_ot=None)
             elif dev_ds is not None:
-                d = dev_ds.collate(mine, func_names=functions or ())
+                # phase 2 of the device collate (two launches, no host wait); phase 1 ran for
+                # the whole epoch at once (prepared)
+                d = dev_ds.fill_batch(prepared[s], func_names=functions or ())
             else:
                 b = data_utils.collate_arrays(stock_paths[mine], observed_dates[mine],
                                               nb_obs[mine], delta_t, funcs)
                 d = _device_batch(b, device)
             return idx, lo, mine, d
 
+        prepared = None
+        if dev_ds is not None and n_steps > 0:
+            # per-time observation counts of every batch of the epoch: all count kernels
+            # enqueued back to back, ONE copy to the host, ONE wait (device_data.prepare_batches)
+            shards = []
+            for s_ in range(n_steps):
+                idx_ = order[s_ * batch_size:(s_ + 1) * batch_size]
+                lo_, hi_ = parallel.shard_range(len(idx_), world, rank)
+                shards.append(idx_[lo_:hi_])
+            live = [i for i, m_ in enumerate(shards) if len(m_)]
+            prepared = [None] * n_steps
+            for i, pr in zip(live, dev_ds.prepare_batches([shards[i] for i in live])):
+                prepared[i] = pr
         # (NJODE_PLAN_AHEAD=0: A/B switch for the look-ahead)
         plan_ahead = plan_ahead and os.environ.get('NJODE_PLAN_AHEAD', '1') != '0'
         nxt = prepare(0) if n_steps > 0 else None
         for s in range(n_steps):
             idx, lo, mine, d = nxt
+            if d.get('ready') is not None:
+                torch.cuda.current_stream().wait_event(d['ready'])
             # one batch ahead: the next batch is collated now, and (fused loop) its execution
             # plan is built on a helper stream beside this step (NJODE.prefetch_plan)
             nxt = prepare(s + 1) if s + 1 < n_steps else None
@@ -180,8 +197,10 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             # is host-bound and the extra call costs 15 %, profiles/r02_producer_bench.jsonl)
             if plan_ahead and fused and nxt is not None and len(nxt[2]) >= 4096:
                 dn = nxt[3]
+                if dn.get('ready') is not None:
+                    torch.cuda.current_stream().wait_event(dn['ready'])
                 model.prefetch_plan(dn['times'], dn['time_ptr'], dn['X'], dn['obs_idx'], delta_t, T,
-                                    dn['start_X'], dn['n_obs_ot'])
+                                    dn['start_X'], dn['n_obs_ot'], need_hT=False)
             parallel.configure_model(model, len(idx), lo)
             args = (d['times'], d['time_ptr'], d['X'], d['obs_idx'], delta_t, T, d['start_X'],
                     d['n_obs_ot'])

@@ -22,6 +22,8 @@ Cases:
                           (data_utils.py:56-105): data.npy + metadata.txt, 12 paths
   g8_physionet_eval       physionet_train.evaluate_model protocol (:411-510) on a synthetic
                           stand-in: observe the first half, predict the second half
+  g9_ref_training_curves  (round 3) the shipped metric_id-{1,2,3}.csv columns: what a training
+                          run has to track
 """
 import contextlib
 import copy
@@ -419,8 +421,34 @@ def g8():
     save('g8_physionet_eval', cfg, arrays)
 
 
+def g9():
+    """The training curves the reference ships with its three pre-trained models
+    (data/saved_models/id-{1,2,3}/metric_id-N.csv: 200 epochs of train.py at batch 200, lr 1e-3,
+    dropout 0.1 on the seed-0 20 000-path datasets, split seed 398): per epoch train_loss,
+    eval_loss, optimal_eval_loss.  Data only -- the numbers a training run of the build has to
+    track (tests/test_hip_convergence.py)."""
+    import csv
+    arrays = {}
+    names = {1: 'BlackScholes', 2: 'Heston', 3: 'OrnsteinUhlenbeck'}
+    for i, name in names.items():
+        path = '/root/reference/data/saved_models/id-{0}/metric_id-{0}.csv'.format(i)
+        with open(path) as f:
+            rows = list(csv.reader(f))
+        head = rows[0]
+        cols = {c: np.array([float(r[head.index(c)]) for r in rows[1:]]) for c in
+                ('epoch', 'train_loss', 'eval_loss', 'optimal_eval_loss')}
+        for c, v in cols.items():
+            arrays['{}/{}'.format(name, c)] = v
+        print('    {:18s} epochs {:3d}  eval_loss[1,10,30,200] = {:.5f} {:.5f} {:.5f} {:.5f}  optimal {:.5f}'
+              .format(name, len(cols['epoch']), cols['eval_loss'][0], cols['eval_loss'][9],
+                      cols['eval_loss'][29], cols['eval_loss'][-1], cols['optimal_eval_loss'][0]))
+    with open('/root/reference/data/saved_models/model_overview.csv') as f:
+        desc = list(csv.reader(f))[1][2]
+    save('g9_ref_training_curves', json.loads(desc), arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     for name in which:
         globals()[name]()

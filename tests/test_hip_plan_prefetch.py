@@ -17,7 +17,7 @@ def _step(m, args, kw, prefetch, left=0):
         m.prefetch_plan(*args, **kw)
         assert m._plans
     _, loss = m.loss_and_grad(*args, **kw)
-    assert sum(len(q) for q in m._plans.values()) == left   # one prefetched plan was picked up
+    assert len(m._plans) == left   # one prefetched plan was picked up
     return float(loss), m.flat_grad().clone()
 
 
@@ -70,7 +70,7 @@ def test_autograd_route_picks_a_prefetched_plan_up():
         for p in m.parameters():
             p.grad = None
         if prefetch:
-            m.prefetch_plan(*args, need_hT=True)
+            m.prefetch_plan(*args)         # default: made for a call that returns hT
         hT, loss = m(*args)
         loss.backward()
         assert not m._plans
@@ -79,3 +79,48 @@ def test_autograd_route_picks_a_prefetched_plan_up():
     h0, l0, g0 = run(False)
     h1, l1, g1 = run(True)
     assert l1 == l0 and torch.equal(h1, h0) and torch.equal(g1, g0)
+
+
+def _demo_args(n_paths, seed):
+    b, meta = bs_batch(n_paths, seed=seed)
+    b = to_dev(b)
+    obs_idx = b['obs_idx'].cuda().int()
+    return (b['times'], b['time_ptr'], b['X'], obs_idx, meta['dt'], meta['maturity'], b['start_X'],
+            b['n_obs_ot'])
+
+
+def test_a_plan_is_only_taken_by_the_very_batch_it_was_made_for():
+    """plans were keyed by id(obs_idx), id(time_ptr) without keeping the objects
+    alive.  Now a plan holds its batch's objects, is matched by identity, and a plan that does
+    not fit the call (no tail order although hT is wanted; obs_idx modified in place) is dropped
+    instead of used or left to block the queue."""
+    cfg = demo_cfg(dropout=0.0, device_outputs=True)
+    torch.manual_seed(0)
+    m = models.NJODE(**cfg).cuda().train()
+    a = _demo_args(300, seed=4)
+    b = _demo_args(300, seed=5)          # same sizes possible, different rows
+    l_a = float(m.loss_and_grad(*a)[1])
+    l_b = float(m.loss_and_grad(*b)[1])
+    # 1. a prefetched plan of batch a is NOT picked up by batch b
+    m.prefetch_plan(*a, need_hT=False)
+    assert float(m.loss_and_grad(*b)[1]) == l_b and len(m._plans) == 1
+    assert float(m.loss_and_grad(*a)[1]) == l_a and not m._plans
+    # 2. a handle is accepted by the call it is passed to, exactly once
+    h = m.prefetch_plan(*a, need_hT=False)
+    assert float(m.loss_and_grad(*a, plan=h)[1]) == l_a and not m._plans
+    with pytest.raises(RuntimeError):
+        m.loss_and_grad(*a, plan=h)
+    # 3. made without the tail order, then model(...) wants hT: dropped, the call plans in line
+    m.prefetch_plan(*a, need_hT=False)
+    with torch.no_grad():
+        hT, loss = m(*a)
+    assert float(loss) == pytest.approx(l_a, rel=1e-6) and not m._plans
+    assert torch.isfinite(hT).all()
+    # 4. obs_idx modified in place after the prefetch: dropped
+    m.prefetch_plan(*a, need_hT=False)
+    a[3].add_(0)
+    assert float(m.loss_and_grad(*a)[1]) == l_a and not m._plans
+    # 5. an unconsumed plan does not block a later one of another batch
+    m.prefetch_plan(*a, need_hT=False)
+    m.prefetch_plan(*b, need_hT=False)
+    assert float(m.loss_and_grad(*b)[1]) == l_b and len(m._plans) == 1
