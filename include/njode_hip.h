@@ -56,6 +56,15 @@ typedef struct ihipStream_t* njodeStream_t; /* == hipStream_t */
 #define NJODE_F_LOSS_EASY 0x8        /* which_loss == 'easy'        models.py:109-126 */
 #define NJODE_F_USE_RNN 0x10         /* use_rnn: GRU jump           models.py:202-217 */
 
+#define NJODE_MAX_HIDDEN 4 /* hidden layers per network the library accepts */
+
+/* One network of get_ffnn (models.py:140-166): nn_desc = ((width, act), ...). */
+typedef struct NjodeNet {
+  int32_t n_hidden;                 /* len(nn_desc); 0 for nn_desc = None (one Linear)   */
+  int32_t width[NJODE_MAX_HIDDEN];  /* width of hidden layer l                            */
+  int32_t act[NJODE_MAX_HIDDEN];    /* NJODE_ACT_* behind hidden layer l                  */
+} NjodeNet;
+
 typedef struct NjodeDims {
   int32_t input_size;  /* d                                                      */
   int32_t hidden_size; /* H                                                      */
@@ -64,6 +73,13 @@ typedef struct NjodeDims {
   int32_t width;       /* width of those hidden layers (ignored if n_hidden==0)  */
   int32_t act;         /* NJODE_ACT_*                                            */
   int32_t flags;       /* NJODE_F_*                                              */
+  /* per_net = 0: ode_nn, enc_nn and readout_nn all are n_hidden layers of `width` units with
+   * `act` (every configuration of the reference's own scripts).  per_net = 1: the three
+   * descriptions follow in nets[] (ode_nn, enc_nn, readout_nn) and n_hidden / width / act are
+   * ignored -- networks that differ from each other, layers of different widths or
+   * activations, up to NJODE_MAX_HIDDEN hidden layers. */
+  int32_t per_net;
+  NjodeNet nets[3];
 } NjodeDims;
 
 /* ---- per-call options ------------------------------------------------------- */
@@ -124,7 +140,12 @@ typedef struct NjodeBatch {
 
 /* ---- queries ----------------------------------------------------------------- */
 
-/* 1 if this build has a gfx950 specialisation for `dims`, else 0. */
+/* 1 if the library runs `dims`, else 0.  Two kernel families stand behind the same entry
+ * points: shape-specialised kernels for the shapes of the build table (njode_build_info lists
+ * them: the demo / PhysioNet / convergence-study shapes with widths < 64, the GRU jump), and
+ * the shape-generic matrix-core kernels (njode_gen.h) for everything else without use_rnn:
+ * any sizes, widths up to NJODE_GEN_MAX_WIDTH, per-network descriptions (per_net = 1). */
+#define NJODE_GEN_MAX_WIDTH 1024
 int njode_supported(const NjodeDims* dims);
 
 /* Length P of the flat parameter vector for `dims` (0 if unsupported). */

@@ -34,10 +34,19 @@ EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
 SDE_MODELS = {'BlackScholes': 0, 'OrnsteinUhlenbeck': 1, 'Heston': 2}
 
 
+MAX_HIDDEN = 4
+
+
+class NjodeNet(C.Structure):
+    _fields_ = [('n_hidden', C.c_int32), ('width', C.c_int32 * MAX_HIDDEN),
+                ('act', C.c_int32 * MAX_HIDDEN)]
+
+
 class NjodeDims(C.Structure):
     _fields_ = [('input_size', C.c_int32), ('hidden_size', C.c_int32),
                 ('output_size', C.c_int32), ('n_hidden', C.c_int32),
-                ('width', C.c_int32), ('act', C.c_int32), ('flags', C.c_int32)]
+                ('width', C.c_int32), ('act', C.c_int32), ('flags', C.c_int32),
+                ('per_net', C.c_int32), ('nets', NjodeNet * 3)]
 
 
 class NjodeSchedule(C.Structure):

@@ -103,8 +103,11 @@ def build(force=False, jobs=None, verbose=True):
                     'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                     'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
                     'njode_mfma_lock4.h')] + [hdr]
+    gen_deps = [os.path.join(CSRC, n) for n in
+                ('njode_gen.hip', 'njode_gen.h', 'njode_gen_host.h', 'njode_device.h',
+                 'njode_error.h')] + [hdr]
     api_deps = [os.path.join(CSRC, n) for n in
-                ('njode_api.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
+                ('njode_api.hip', 'njode_gen_host.h', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
                  'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                  'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
                  'njode_mfma_lock4.h', 'njode_error.h',
@@ -125,6 +128,9 @@ def build(force=False, jobs=None, verbose=True):
     api_obj = os.path.join(OBJ, 'api.o')
     cmd = common + [os.path.join(CSRC, 'njode_api.hip'), '-o', api_obj]
     tasks.append((api_obj, cmd, _digest(api_deps, ' '.join(cmd))))
+    gen_obj = os.path.join(OBJ, 'gen.o')
+    cmd = common + [os.path.join(CSRC, 'njode_gen.hip'), '-o', gen_obj]
+    tasks.append((gen_obj, cmd, _digest(gen_deps, ' '.join(cmd))))
     # the batch producer spells out the reference's float64 expression trees: no contraction
     prod_obj = os.path.join(OBJ, 'producer.o')
     cmd = common + ['-ffp-contract=off', os.path.join(CSRC, 'njode_producer.hip'), '-o', prod_obj]
@@ -143,7 +149,7 @@ def build(force=False, jobs=None, verbose=True):
     todo = [t for t in tasks if stale(t)]
     parts_only = os.environ.get('NJODE_PARTS_ONLY', '').strip()   # maintainer aid, e.g. "0": a change
     if parts_only:                                                 # that only touches those parts
-        keep = tuple('_{}.o'.format(x) for x in parts_only.split(',')) + ('api.o', 'producer.o')
+        keep = tuple('_{}.o'.format(x) for x in parts_only.split(',')) + ('api.o', 'producer.o', 'gen.o')
         for t in todo:
             if not t[0].endswith(keep) and os.path.exists(t[0]):
                 with open(t[0] + '.stamp', 'w') as f:

@@ -1,0 +1,893 @@
+// njode_gen.h -- shape-generic NJ-ODE kernels on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// The specialised kernels (njode_mfma*.h, njode_ode2.h) keep a layer's units in registers and
+// a network's A-fragments in VGPRs / LDS, so every model shape is a template instantiation and
+// a layer wider than 63 units does not fit.  This family takes the shape at RUN TIME:
+// any input / hidden / output size, per network any number of hidden layers (<= GEN_MAXL - 1)
+// of any widths with tanh or relu each, the three networks independent of each other, masked or
+// not, every residual case, dropout.  It serves every shape the build table has no
+// specialisation for (reference grids: widths 80 ... 400, nn_desc = None with hidden_size 50 /
+// 100, the climate shape d = 5: NJODE/parallel_train.py:304-305, 366-371, 433-470, 609, 650,
+// 712), on the lockstep plan (one chain per path over the shared grid, models.py:430-511).
+//
+// Execution model
+//   * one workgroup (NW waves) advances a TILE of 16 paths; vectors over the tile live in LDS
+//     images img[unit][chain] (16 floats = one 64-byte row per unit);
+//   * a layer is out = W in: the A operand (16 output units x 4 input units) streams from a
+//     packed fragment table in global memory (L2-resident: every workgroup reads the same
+//     table), the B operand (4 input units x 16 chains) is one ds_read_b32 of the input image,
+//     wave w owns the output tiles [w per, (w + 1) per); bias = the constant-1 row behind the
+//     inputs; the epilogue applies activation + dropout and writes the output image;
+//   * training calls store every layer input of every network evaluation (one record per
+//     (Euler step | jump time, tile)); the adjoint sweep walks the events in reverse with the
+//     transposed fragment tables and stores the delta of every layer output next to it;
+//   * weight gradients are then plain GEMMs over those records, dW = sum_records delta x input,
+//     K = the 16 chains of a record: one float4 load per operand tile carries all four k-steps
+//     (k_gen_dw); slabs + fixed-order reduction, no float atomics.
+#pragma once
+#include "njode_device.h"
+
+namespace njode {
+namespace gen {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+NJ_DEV f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int GEN_MAXL = 5;      // layers per network (<= 4 hidden layers)
+constexpr int QU = 4;            // k-steps are padded to a multiple of QU (prefetch depth)
+constexpr uint32_t G_NET_ODE = 0, G_NET_ENC = 1, G_NET_DEC = 2, G_NET_DEC_BJ = 3, G_NET_DEC_ROW = 4;
+constexpr uint32_t G_TKEY_START = 0xffffffffu;
+
+struct GLayer {
+  int n_in, n_out;      // units in / out (bias not counted)
+  int act;              // activation of the OUTPUT (ACT_TANH / ACT_RELU); -1: linear (last layer)
+  int w_off, b_off;     // offsets of W [out][in] and b [out] in the flat parameter vector
+  int f_off, ft_off;    // fragment tables (floats from the table base): forward, transposed
+  int Qp, MT;           // forward: k-steps (inputs + bias, padded to QU), output tiles of 16
+  int QTp, MTT;         // transposed: k-steps over the outputs (padded), tiles over the inputs
+  int a_row, d_row;     // record rows: this layer's INPUT vector / the delta of its OUTPUT
+};
+struct GNet {
+  int nl;               // layers = hidden layers + 1
+  int rec_rows;         // rows (of 16 floats) of one evaluation record
+  int n_in, n_out;
+  GLayer l[GEN_MAXL];
+};
+
+struct GArgs {
+  const float* P;
+  const float* frag;
+  GNet ode, enc, dec;
+  int D, H, DO, IN0;
+  int masked, curt, enc_case, enc_mult, dec_case, dec_mult, loss_easy;
+  int B, T, n_obs, K, n_times;
+  const float* start_X;
+  const float* X;
+  const float* M;
+  const int* n_obs_ot;
+  float inv_batch;
+  unsigned long long gid0;
+  const float* step_dt;
+  const float* step_t;
+  const float* time_f32;
+  const int* jlo;        // [K + 2] first time index whose jump happens at Euler step >= k
+  const int* dense;      // [n_times][B] row of path b at time i, or -1
+  float* rec_ode;        // [K][T] records
+  float* rec_enc;        // [n_times][T] jump records, then [T] start records
+  float* rec_dec;        // [n_times][T][2]: readout before the jump, readout after it
+  float* ybuf;           // [n_times][T][2][DO][16]: y_bj, y
+  int* flags;            // [n_times][T] 1: the tile had an observation at this time
+  float* hT;
+  float* path_h;
+  float* path_y;
+  float* loss_terms;     // [B]
+  int save, want_path, want_loss, drop;
+  DropCtx dc;
+  float keep, weight;
+  int img_rows;          // rows of one ping-pong image
+};
+
+// ---- LDS carve-up (floats), identical in the forward and the sweep --------------------------
+struct GLds {
+  lfp img0, img1, h, tx, y, ybj, xin, mk, hn, xr, misc;
+  int* rows;
+  NJ_DEV void carve(lfp base, const GArgs& a) {
+    lfp p = base;
+    const int mx = a.D > a.DO ? a.D : a.DO;
+    img0 = p; p += a.img_rows * 16;
+    img1 = p; p += a.img_rows * 16;
+    h = p; p += a.H * 16;
+    tx = p; p += a.D * 16;
+    y = p; p += mx * 16;
+    ybj = p; p += mx * 16;
+    xin = p; p += mx * 16;
+    mk = p; p += mx * 16;
+    hn = p; p += a.H * 16;
+    xr = p; p += mx * 16;
+    misc = p; p += 8 * 16;     // tau, loss, scale, lam scratch ...
+    rows = (int*)p;
+  }
+};
+__host__ __device__ inline int gen_lds_floats(int img_rows, int D, int H, int DO) {
+  const int mx = D > DO ? D : DO;
+  return 2 * img_rows * 16 + 2 * H * 16 + D * 16 + 5 * mx * 16 + 8 * 16 + 16;
+}
+
+NJ_DEV float tanh_acc(float x) {   // few-ulp tanh (njode_device.h, NJ_ACC_TANH form)
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float x2 = x * x;
+  float p = fmaf(x2, -8.8632355299021965e-3f, 2.1869488536155203e-2f);
+  p = fmaf(x2, p, -5.3968253968253971e-2f);
+  p = fmaf(x2, p, 1.3333333333333333e-1f);
+  p = fmaf(x2, p, -3.3333333333333331e-1f);
+  const float s = fmaf(x * x2, p, x);
+  return fabsf(x) < 0.3f ? s : t;
+}
+NJ_DEV float act_rt(int act, float z) { return act == ACT_TANH ? tanh_acc(z) : fmaxf(z, 0.0f); }
+NJ_DEV float dact_rt(int act, float av) { return act == ACT_TANH ? 1.0f - av * av : (av > 0.0f ? 1.0f : 0.0f); }
+
+// dropout: one hash per (call seed, global path, time key, network) and chain, one fmix per unit
+NJ_DEV uint32_t drop_base(const DropCtx& dc, unsigned long long gid, uint32_t tkey, uint32_t net) {
+  return drop_state(dc, (uint32_t)gid, (uint32_t)(gid >> 32), tkey, net);
+}
+NJ_DEV bool drop_keep(uint32_t base, int layer, int unit, uint32_t thr16) {
+  const uint32_t h = fmix32(base ^ ((uint32_t)layer * 0x9e3779b9u + (uint32_t)unit * 0x85ebca6bu + 0x632be5abu));
+  return (h >> 16) >= thr16;
+}
+
+// ---- one matrix product of a tile: acc[t] = A(tile mt0 + t) x in, t < TT --------------------
+// ft: fragment table of the layer ([tile][Qp][64 lanes]); in: LDS image (16 floats per unit)
+template <int TT>
+NJ_DEV void mfma_tiles(const float* __restrict__ ft, int Qp, int mt0, lfp in, int lane, f32x4 (&acc)[TT]) {
+  const int g = lane >> 4, c = lane & 15;
+  const float* fp = ft + (size_t)mt0 * Qp * 64 + lane;
+  lfp bp = in + g * 16 + c;
+  float an[QU][TT];
+#pragma unroll
+  for (int u = 0; u < QU; ++u)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) an[u][t] = fp[((size_t)t * Qp + u) * 64];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < Qp; q0 += QU) {
+    float ac[QU][TT];
+#pragma unroll
+    for (int u = 0; u < QU; ++u)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) ac[u][t] = an[u][t];
+    if (q0 + QU < Qp) {
+#pragma unroll
+      for (int u = 0; u < QU; ++u)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) an[u][t] = fp[((size_t)t * Qp + q0 + QU + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < QU; ++u) {
+      const float b = bp[(q0 + u) * 64];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) acc[t] = mfma4(ac[u][t], b, acc[t]);
+    }
+  }
+}
+
+// all tiles [0, MT) of one product, spread over the workgroup's waves; epi(mt, acc) per tile
+template <class EPI>
+NJ_DEV void layer_product(const float* __restrict__ ft, int Qp, int MT, lfp in, EPI epi) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int per = (MT + nw - 1) / nw;
+  int mt = wv * per;
+  const int end = mt + per < MT ? mt + per : MT;
+  while (end - mt >= 4) {
+    f32x4 acc[4];
+    mfma_tiles<4>(ft, Qp, mt, in, lane, acc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) epi(mt + t, acc[t]);
+    mt += 4;
+  }
+  if (end - mt >= 2) {
+    f32x4 acc[2];
+    mfma_tiles<2>(ft, Qp, mt, in, lane, acc);
+    epi(mt, acc[0]);
+    epi(mt + 1, acc[1]);
+    mt += 2;
+  }
+  if (end - mt >= 1) {
+    f32x4 acc[1];
+    mfma_tiles<1>(ft, Qp, mt, in, lane, acc);
+    epi(mt, acc[0]);
+  }
+}
+
+// ---- forward of one network on the tile -----------------------------------------------------
+// `in` holds the n_in input rows; returns the image that holds the n_out output rows.
+// rec != null: the layer inputs are stored to the evaluation record (training calls).
+// dbase: per-chain dropout hash base of this evaluation (lane's chain = lane & 15)
+NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* rec, bool drop,
+                       uint32_t dbase) {
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  for (int l = 0; l < N.nl; ++l) {
+    const GLayer L = N.l[l];
+    if (tid < 16) in[L.n_in * 16 + tid] = 1.0f;             // bias unit
+    if (rec) {
+      float* dst = rec + (size_t)L.a_row * 16;
+      for (int e = tid; e < L.n_in * 16; e += nth) dst[e] = in[e];
+    }
+    __syncthreads();
+    const bool hidden = l + 1 < N.nl;
+    layer_product(a.frag + L.f_off, L.Qp, L.MT, in, [&](int mt, const f32x4& acc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 16 * mt + 4 * g + r;
+        if (u < L.n_out) {
+          float v = acc[r];
+          if (hidden) {
+            v = act_rt(L.act, v);
+            if (drop) v = drop_keep(dbase, l, u, a.dc.thr16) ? v * a.dc.inv_keep : -0.0f;
+          }
+          other[u * 16 + c] = v;
+        }
+      }
+    });
+    __syncthreads();
+    lfp t = in; in = other; other = t;
+  }
+  return in;
+}
+
+// ---- adjoint of one network evaluation ------------------------------------------------------
+// `din` holds the delta of the network output (n_out rows; zero for chains that take no part).
+// Stores the delta of every layer output to the record (for the weight gradients) and leaves
+// the gradient w.r.t. the network INPUT vector in the returned image (n_in rows), unless
+// !need_input (then the first layer's transposed product is skipped).
+NJ_DEV lfp net_backward(const GArgs& a, const GNet& N, lfp din, lfp other, float* rec, bool drop,
+                        bool need_input) {
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  for (int l = N.nl - 1; l >= 0; --l) {
+    const GLayer L = N.l[l];
+    {
+      float* dst = rec + (size_t)L.d_row * 16;
+      for (int e = tid; e < L.n_out * 16; e += nth) dst[e] = din[e];
+      // rows up to the padded k range must be finite: they meet zero fragments
+      for (int e = L.n_out * 16 + tid; e < L.QTp * 64; e += nth) din[e] = 0.0f;
+    }
+    __syncthreads();
+    if (l == 0 && !need_input) break;
+    const float* acts = rec + (size_t)L.a_row * 16;        // this layer's input = act of layer l-1
+    const int pact = l > 0 ? N.l[l - 1].act : -1;
+    layer_product(a.frag + L.ft_off, L.QTp, L.MTT, din, [&](int mt, const f32x4& acc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int u = 16 * mt + 4 * g + r;
+        if (u < L.n_in) {
+          float v = acc[r];
+          if (l > 0) {
+            const float av = acts[u * 16 + c];
+            if (drop) {
+              const bool dropped = __float_as_uint(av) == 0x80000000u;
+              v = dropped ? 0.0f : v * a.dc.inv_keep * dact_rt(pact, av * a.keep);
+            } else {
+              v *= dact_rt(pact, av);
+            }
+          }
+          other[u * 16 + c] = v;
+        }
+      }
+    });
+    __syncthreads();
+    lfp t = din; din = other; other = t;
+  }
+  return din;
+}
+
+// ---- small tile helpers ---------------------------------------------------------------------
+// encoder input [tanh(x) ; mask] into `in` (models.py:261-276: ffnn(cat(tanh(x), mask)))
+NJ_DEV void enc_input(const GArgs& a, lfp in, lfp x, lfp mask) {
+  for (int e = threadIdx.x; e < a.D * 16; e += blockDim.x) {
+    in[e] = tanh_acc(x[e]);
+    if (a.masked) in[a.D * 16 + e] = mask[e];
+  }
+}
+// identity path of the encoder added to its output: out[j] += f(x)   (raw x, models.py:240-259)
+NJ_DEV void enc_residual(const GArgs& a, lfp out, lfp x) {
+  if (a.enc_case == 0) return;
+  for (int e = threadIdx.x; e < a.H * 16; e += blockDim.x) {
+    const int j = e >> 4, c = e & 15;
+    float s;
+    if (a.enc_case == 1) s = x[(j % a.D) * 16 + c];
+    else {
+      s = 0.0f;
+      for (int q = 0; q < a.enc_mult; ++q) s += x[(q * a.H + j) * 16 + c];
+      s *= 1.0f / a.enc_mult;
+    }
+    out[e] += s;
+  }
+}
+NJ_DEV void dec_input(const GArgs& a, lfp in, lfp h) {
+  for (int e = threadIdx.x; e < a.H * 16; e += blockDim.x) in[e] = tanh_acc(h[e]);
+}
+NJ_DEV void dec_residual(const GArgs& a, lfp out, lfp h) {
+  if (a.dec_case == 0) return;
+  for (int e = threadIdx.x; e < a.DO * 16; e += blockDim.x) {
+    const int j = e >> 4, c = e & 15;
+    float s;
+    if (a.dec_case == 1) s = h[(j % a.H) * 16 + c];
+    else {
+      s = 0.0f;
+      for (int q = 0; q < a.dec_mult; ++q) s += h[(q * a.DO + j) * 16 + c];
+      s *= 1.0f / a.dec_mult;
+    }
+    out[e] += s;
+  }
+}
+NJ_DEV void copy_rows(lfp dst, lfp src, int rows) {
+  for (int e = threadIdx.x; e < rows * 16; e += blockDim.x) dst[e] = src[e];
+}
+
+// paper loss of the tile's observed chains (models.py:71-126) and its gradients; one thread per
+// chain.  has[c]: chain c has an observation.  dy / dybj may be null (forward).
+NJ_DEV void loss_tile(const GArgs& a, lfp x, lfp mask, lfp y, lfp ybj, const int* rows, lfp scale,
+                      lfp loss_acc, lfp dy, lfp dybj) {
+  const int c = threadIdx.x;
+  if (c < 16) {
+    const bool has = rows[c] >= 0;
+    float sa = 0.0f, sb = 0.0f;
+    for (int q = 0; q < a.D; ++q) {
+      const float m = a.masked ? mask[q * 16 + c] : 1.0f;
+      const float e = x[q * 16 + c] - y[q * 16 + c];
+      const float f = a.loss_easy ? (ybj[q * 16 + c] - x[q * 16 + c]) : (ybj[q * 16 + c] - y[q * 16 + c]);
+      sa = fmaf(m * e, e, sa);
+      sb = fmaf(m * f, f, sb);
+    }
+    const float na = sqrtf(sa + 1e-10f), nb = sqrtf(sb + 1e-10f);
+    const float w = a.weight;
+    const float ca = a.loss_easy ? w : 2.0f * w, cb = a.loss_easy ? (1.0f - w) : 2.0f * (1.0f - w);
+    const float s = ca * na + cb * nb;
+    const float sc = has ? scale[c] : 0.0f;
+    if (loss_acc) loss_acc[c] += s * s * sc;
+    if (dy) {
+      const float gq = 2.0f * s * sc;
+      const float ga = gq * ca / na, gb = gq * cb / nb;
+      for (int q = 0; q < a.D; ++q) {
+        const float m = a.masked ? mask[q * 16 + c] : 1.0f;
+        const float e = x[q * 16 + c] - y[q * 16 + c];
+        if (a.loss_easy) {
+          const float f = ybj[q * 16 + c] - x[q * 16 + c];
+          dy[q * 16 + c] = -ga * m * e;
+          dybj[q * 16 + c] = gb * m * f;
+        } else {
+          const float f = ybj[q * 16 + c] - y[q * 16 + c];
+          dy[q * 16 + c] = -ga * m * e - gb * m * f;
+          dybj[q * 16 + c] = gb * m * f;
+        }
+      }
+    }
+  }
+}
+
+// ODE input vector of the tile (models.py:188-199): [tanh(last_X), tanh(h), tau, t - tau (, t)]
+NJ_DEV void ode_input(const GArgs& a, lfp in, lfp tx, lfp h, lfp tau, float t) {
+  const int n = (a.D + a.H) * 16;
+  for (int e = threadIdx.x; e < n; e += blockDim.x)
+    in[e] = e < a.D * 16 ? tx[e] : tanh_acc(h[e - a.D * 16]);
+  if (threadIdx.x < 16) {
+    const int c = threadIdx.x;
+    const float ta = tau[c], td = t - ta;
+    in[(a.D + a.H) * 16 + c] = ta;
+    in[(a.D + a.H + 1) * 16 + c] = td;
+    if (a.curt) in[(a.D + a.H + 2) * 16 + c] = ta + td;
+  }
+}
+
+// =============================================================================================
+// forward: one workgroup per tile of 16 paths (models.py:379-518)
+// =============================================================================================
+__global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  GLds S;
+  S.carve((lfp)smem, a);
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int tile = blockIdx.x, b0 = tile * 16;
+  {
+    const int n = gen_lds_floats(a.img_rows, a.D, a.H, a.DO);
+    for (int e = tid; e < n; e += nth) ((lfp)smem)[e] = 0.0f;
+  }
+  __syncthreads();
+  lfp tau = S.misc, lossacc = S.misc + 16, scale = S.misc + 32;
+  const int cch = tid & 15;                                  // chain of this lane in epilogues
+  const int bch = b0 + cch < a.B ? b0 + cch : a.B - 1;
+  const unsigned long long gidc = a.gid0 + (unsigned long long)bch;
+  if (tid < 16) {
+    const int b = b0 + tid;
+    scale[tid] = (b < a.B && a.want_loss) ? a.inv_batch / (float)a.n_obs_ot[b] : 0.0f;
+  }
+  // ---- h = encoder(start_X) with a zero mask (models.py:411-414)
+  for (int e = tid; e < a.D * 16; e += nth) {
+    const int q = e >> 4, c = e & 15, b = b0 + c;
+    const float v = b < a.B ? a.start_X[(size_t)b * a.D + q] : 0.0f;
+    S.xr[e] = v;
+    S.tx[e] = tanh_acc(v);
+    S.mk[e] = 0.0f;
+  }
+  __syncthreads();
+  enc_input(a, S.img0, S.xr, S.mk);
+  __syncthreads();
+  {
+    float* rec = a.save ? a.rec_enc + ((size_t)a.n_times * a.T + tile) * a.enc.rec_rows * 16 : nullptr;
+    lfp out = net_forward(a, a.enc, S.img0, S.img1, rec, a.drop != 0,
+                          drop_base(a.dc, gidc, G_TKEY_START, G_NET_ENC));
+    copy_rows(S.h, out, a.H);
+    __syncthreads();
+    enc_residual(a, S.h, S.xr);
+    __syncthreads();
+  }
+  int prow = 0;
+  auto emit_row = [&](uint32_t tkey) {   // path output: readout of the current state
+    if (!a.want_path) return;
+    dec_input(a, S.img0, S.h);
+    __syncthreads();
+    lfp out = net_forward(a, a.dec, S.img0, S.img1, nullptr, a.drop != 0,
+                          drop_base(a.dc, gidc, tkey, G_NET_DEC_ROW));
+    copy_rows(S.y, out, a.DO);
+    __syncthreads();
+    dec_residual(a, S.y, S.h);
+    __syncthreads();
+  };
+  auto write_row = [&]() {
+    if (!a.want_path) return;
+    const int nv = a.B - b0 < 16 ? a.B - b0 : 16;
+    float* ph = a.path_h + ((size_t)prow * a.B + b0) * a.H;
+    for (int e = tid; e < nv * a.H; e += nth) ph[e] = S.h[(e % a.H) * 16 + e / a.H];
+    float* py = a.path_y + ((size_t)prow * a.B + b0) * a.DO;
+    for (int e = tid; e < nv * a.DO; e += nth) py[e] = S.y[(e % a.DO) * 16 + e / a.DO];
+    ++prow;
+  };
+  emit_row(G_TKEY_START - 1);
+  write_row();
+
+  for (int k = 0;; ++k) {
+    // ---- jumps that happen before Euler step k
+    for (int i = a.jlo[k]; i < a.jlo[k + 1]; ++i) {
+      if (tid < 16) S.rows[tid] = (b0 + tid < a.B && a.n_obs > 0) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
+      __syncthreads();
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) any |= S.rows[c] >= 0;
+      if (any) {
+        const size_t jrec = (size_t)i * a.T + tile;
+        // y_bj = readout(h)
+        dec_input(a, S.img0, S.h);
+        __syncthreads();
+        {
+          float* rec = a.save ? a.rec_dec + (jrec * 2 + 0) * a.dec.rec_rows * 16 : nullptr;
+          lfp out = net_forward(a, a.dec, S.img0, S.img1, rec, a.drop != 0,
+                                drop_base(a.dc, gidc, (uint32_t)k, G_NET_DEC_BJ));
+          copy_rows(S.ybj, out, a.DO);
+          __syncthreads();
+          dec_residual(a, S.ybj, S.h);
+        }
+        // observation, mask, encoder input (self-imputation in masked mode, models.py:463-467)
+        for (int e = tid; e < a.D * 16; e += nth) {
+          const int q = e >> 4, c = e & 15, r = S.rows[c];
+          const float xv = r >= 0 ? a.X[(size_t)r * a.D + q] : 0.0f;
+          const float mv = a.masked ? (r >= 0 ? a.M[(size_t)r * a.D + q] : 0.0f) : 1.0f;
+          S.xr[e] = xv;
+          S.mk[e] = mv;
+        }
+        __syncthreads();
+        for (int e = tid; e < a.D * 16; e += nth)
+          S.xin[e] = a.masked ? S.xr[e] * S.mk[e] + (1.0f - S.mk[e]) * S.ybj[e] : S.xr[e];
+        __syncthreads();
+        enc_input(a, S.img0, S.xin, S.mk);
+        __syncthreads();
+        {
+          float* rec = a.save ? a.rec_enc + jrec * a.enc.rec_rows * 16 : nullptr;
+          lfp out = net_forward(a, a.enc, S.img0, S.img1, rec, a.drop != 0,
+                                drop_base(a.dc, gidc, (uint32_t)k, G_NET_ENC));
+          copy_rows(S.hn, out, a.H);
+          __syncthreads();
+          enc_residual(a, S.hn, S.xin);
+          __syncthreads();
+        }
+        // y = readout(h_new); chains without an observation keep their state: evaluate the
+        // readout on the state they will have after the commit
+        for (int e = tid; e < a.H * 16; e += nth)
+          if (S.rows[e & 15] < 0) S.hn[e] = S.h[e];
+        __syncthreads();
+        dec_input(a, S.img0, S.hn);
+        __syncthreads();
+        {
+          float* rec = a.save ? a.rec_dec + (jrec * 2 + 1) * a.dec.rec_rows * 16 : nullptr;
+          lfp out = net_forward(a, a.dec, S.img0, S.img1, rec, a.drop != 0,
+                                drop_base(a.dc, gidc, (uint32_t)k, G_NET_DEC));
+          // (path output: unobserved chains keep the y of their last row, as the reference's
+          // whole-batch readout gives them in eval mode)
+          for (int e = tid; e < a.DO * 16; e += nth)
+            if (S.rows[e & 15] >= 0 || !a.want_path) S.y[e] = out[e];
+          __syncthreads();
+          for (int e = tid; e < a.DO * 16; e += nth) {
+            if (S.rows[e & 15] >= 0 || !a.want_path) {
+              const int j = e >> 4, c = e & 15;
+              float s = 0.0f;
+              if (a.dec_case == 1) s = S.hn[(j % a.H) * 16 + c];
+              else if (a.dec_case == 2) {
+                for (int q = 0; q < a.dec_mult; ++q) s += S.hn[(q * a.DO + j) * 16 + c];
+                s *= 1.0f / a.dec_mult;
+              }
+              S.y[e] += s;
+            }
+          }
+          __syncthreads();
+        }
+        if (a.want_loss) loss_tile(a, S.xr, S.mk, S.y, S.ybj, S.rows, scale, lossacc, nullptr, nullptr);
+        if (a.save) {
+          float* yb = a.ybuf + jrec * 2 * a.DO * 16;
+          for (int e = tid; e < a.DO * 16; e += nth) {
+            yb[e] = S.ybj[e];
+            yb[a.DO * 16 + e] = S.y[e];
+          }
+          if (tid == 0) a.flags[jrec] = 1;
+        }
+        // commit (models.py:468-489): h <- h_new, last_X <- X_obs (masked: Y), tau <- obs time
+        for (int e = tid; e < a.H * 16; e += nth)
+          if (S.rows[e & 15] >= 0) S.h[e] = S.hn[e];
+        for (int e = tid; e < a.D * 16; e += nth)
+          if (S.rows[e & 15] >= 0) S.tx[e] = tanh_acc(a.masked ? S.y[e] : S.xr[e]);
+        if (tid < 16 && S.rows[tid] >= 0) tau[tid] = a.time_f32[i];
+        __syncthreads();
+      }
+      write_row();
+      __syncthreads();
+    }
+    if (k >= a.K) break;
+    // ---- Euler step k (models.py:369-377)
+    {
+      const float dt = a.step_dt[k], t = a.step_t[k];
+      ode_input(a, S.img0, S.tx, S.h, tau, t);
+      __syncthreads();
+      float* rec = a.save ? a.rec_ode + ((size_t)k * a.T + tile) * a.ode.rec_rows * 16 : nullptr;
+      lfp out = net_forward(a, a.ode, S.img0, S.img1, rec, a.drop != 0,
+                            drop_base(a.dc, gidc, (uint32_t)k, G_NET_ODE));
+      for (int e = tid; e < a.H * 16; e += nth) S.h[e] = fmaf(dt, out[e], S.h[e]);
+      __syncthreads();
+      emit_row(0x80000000u + (uint32_t)k);
+      write_row();
+    }
+  }
+  if (a.hT) {
+    const int nv = a.B - b0 < 16 ? a.B - b0 : 16;
+    float* ph = a.hT + (size_t)b0 * a.H;
+    for (int e = tid; e < nv * a.H; e += nth) ph[e] = S.h[(e % a.H) * 16 + e / a.H];
+  }
+  if (a.want_loss && tid < 16 && b0 + tid < a.B) a.loss_terms[b0 + tid] = lossacc[tid];
+}
+
+// =============================================================================================
+// adjoint sweep: events of the tile in reverse (same mathematics as njode_lockstep_bwd.h)
+// =============================================================================================
+__global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  GLds S;
+  S.carve((lfp)smem, a);
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int tile = blockIdx.x, b0 = tile * 16;
+  {
+    const int n = gen_lds_floats(a.img_rows, a.D, a.H, a.DO);
+    for (int e = tid; e < n; e += nth) ((lfp)smem)[e] = 0.0f;
+  }
+  __syncthreads();
+  lfp scale = S.misc + 32;
+  if (tid < 16) {
+    const int b = b0 + tid;
+    scale[tid] = b < a.B ? a.inv_batch / (float)a.n_obs_ot[b] : 0.0f;
+  }
+  // adjoints: lam_h = S.h [H], lam_x = S.tx [D] (w.r.t. last_X, masked models)
+  lfp lam_h = S.h, lam_x = S.tx, dy = S.y, dybj = S.ybj, lam_hn = S.hn;
+  const bool drop = a.drop != 0;
+  __syncthreads();
+  for (int k = a.K; k >= 0; --k) {
+    if (k < a.K) {
+      // ---- reverse Euler step k: h' = h + dt f(in0)
+      float* rec = a.rec_ode + ((size_t)k * a.T + tile) * a.ode.rec_rows * 16;
+      const float dt = a.step_dt[k];
+      for (int e = tid; e < a.H * 16; e += nth) S.img0[e] = dt * lam_h[e];
+      __syncthreads();
+      lfp din = net_backward(a, a.ode, S.img0, S.img1, rec, drop, true);
+      const float* in0 = rec + (size_t)a.ode.l[0].a_row * 16;
+      for (int e = tid; e < a.H * 16; e += nth) {
+        const float th = in0[a.D * 16 + e];
+        lam_h[e] = fmaf(din[a.D * 16 + e], 1.0f - th * th, lam_h[e]);
+      }
+      if (a.masked) {
+        for (int e = tid; e < a.D * 16; e += nth) {
+          const float t = in0[e];
+          lam_x[e] = fmaf(din[e], 1.0f - t * t, lam_x[e]);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- reverse the jumps the forward applied right before step k
+    for (int i = a.jlo[k + 1] - 1; i >= a.jlo[k]; --i) {
+      const size_t jrec = (size_t)i * a.T + tile;
+      if (!a.flags[jrec]) continue;                           // workgroup-uniform
+      if (tid < 16) S.rows[tid] = (b0 + tid < a.B) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
+      // observation, mask, stored readouts
+      {
+        const float* yb = a.ybuf + jrec * 2 * a.DO * 16;
+        __syncthreads();
+        for (int e = tid; e < a.D * 16; e += nth) {
+          const int q = e >> 4, c = e & 15, r = S.rows[c];
+          S.xr[e] = r >= 0 ? a.X[(size_t)r * a.D + q] : 0.0f;
+          S.mk[e] = a.masked ? (r >= 0 ? a.M[(size_t)r * a.D + q] : 0.0f) : 1.0f;
+          S.xin[e] = yb[e];                 // y_bj
+          S.img1[e] = yb[a.DO * 16 + e];    // y
+        }
+        __syncthreads();
+        loss_tile(a, S.xr, S.mk, S.img1, S.xin, S.rows, scale, nullptr, dy, dybj);
+        __syncthreads();
+      }
+      // unobserved chains: no loss, and their state passed through the jump unchanged
+      for (int e = tid; e < a.DO * 16; e += nth) {
+        const bool has = S.rows[e & 15] >= 0;
+        float v = has ? dy[e] : 0.0f;
+        if (has && a.masked) v += lam_x[e];     // last_X <- Y: the next segment's input gradient
+        dy[e] = v;
+        if (!has) dybj[e] = 0.0f;
+      }
+      __syncthreads();
+      // y = readout(h_new)
+      float* rec_y = a.rec_dec + (jrec * 2 + 1) * a.dec.rec_rows * 16;
+      copy_rows(S.img0, dy, a.DO);
+      __syncthreads();
+      {
+        lfp din = net_backward(a, a.dec, S.img0, S.img1, rec_y, drop, true);
+        const float* th = rec_y + (size_t)a.dec.l[0].a_row * 16;
+        for (int e = tid; e < a.H * 16; e += nth) {
+          const int j = e >> 4, c = e & 15;
+          if (S.rows[c] >= 0) {
+            const float t = th[e];
+            float v = din[e] * (1.0f - t * t);
+            if (a.dec_case == 1) {
+              for (int q = j; q < a.DO; q += a.H) v += dy[q * 16 + c];
+            } else if (a.dec_case == 2) {
+              v += dy[(j % a.DO) * 16 + c] * (1.0f / a.dec_mult);
+            }
+            lam_hn[e] = lam_h[e] + v;
+          } else {
+            lam_hn[e] = 0.0f;
+          }
+        }
+        __syncthreads();
+      }
+      // h_new = encoder(x_in, M)
+      float* rec_e = a.rec_enc + jrec * a.enc.rec_rows * 16;
+      copy_rows(S.img0, lam_hn, a.H);
+      __syncthreads();
+      {
+        lfp din = net_backward(a, a.enc, S.img0, S.img1, rec_e, drop, a.masked != 0);
+        if (a.masked) {
+          const float* ein = rec_e + (size_t)a.enc.l[0].a_row * 16;
+          for (int e = tid; e < a.D * 16; e += nth) {
+            const int q = e >> 4, c = e & 15;
+            if (S.rows[c] >= 0) {
+              const float t = ein[e];
+              float v = din[e] * (1.0f - t * t);
+              if (a.enc_case == 1) {
+                for (int j = q; j < a.H; j += a.D) v += lam_hn[j * 16 + c];
+              } else if (a.enc_case == 2) {
+                v += lam_hn[(q % a.H) * 16 + c] * (1.0f / a.enc_mult);
+              }
+              dybj[e] += v * (1.0f - S.mk[e]);
+            }
+          }
+        }
+        __syncthreads();
+      }
+      // y_bj = readout(h_pre): the only path from the state before the jump
+      float* rec_b = a.rec_dec + (jrec * 2 + 0) * a.dec.rec_rows * 16;
+      copy_rows(S.img0, dybj, a.DO);
+      __syncthreads();
+      {
+        lfp din = net_backward(a, a.dec, S.img0, S.img1, rec_b, drop, true);
+        const float* th = rec_b + (size_t)a.dec.l[0].a_row * 16;
+        for (int e = tid; e < a.H * 16; e += nth) {
+          const int j = e >> 4, c = e & 15;
+          if (S.rows[c] >= 0) {
+            const float t = th[e];
+            float v = din[e] * (1.0f - t * t);
+            if (a.dec_case == 1) {
+              for (int q = j; q < a.DO; q += a.H) v += dybj[q * 16 + c];
+            } else if (a.dec_case == 2) {
+              v += dybj[(j % a.DO) * 16 + c] * (1.0f / a.dec_mult);
+            }
+            lam_h[e] = v;
+          }
+        }
+        for (int e = tid; e < a.D * 16; e += nth)
+          if (S.rows[e & 15] >= 0) lam_x[e] = 0.0f;
+        __syncthreads();
+      }
+    }
+  }
+  // ---- start state: h0 = encoder(start_X): its deltas for the weight gradients
+  {
+    float* rec = a.rec_enc + ((size_t)a.n_times * a.T + tile) * a.enc.rec_rows * 16;
+    copy_rows(S.img0, lam_h, a.H);
+    __syncthreads();
+    (void)net_backward(a, a.enc, S.img0, S.img1, rec, drop, false);
+  }
+}
+
+// =============================================================================================
+// weight gradients: dW[o][i] = sum over records and chains of delta[o][chain] * input[i][chain]
+// =============================================================================================
+struct GDw {
+  const float* rec;      // records of this network
+  long long n_rec;       // number of records
+  int rec_floats;        // floats per record
+  const int* flags;      // per flag group 0 / 1, or null (all active)
+  int flag_div;          // record r belongs to flag group r / flag_div
+  long long n_flagged;   // records [0, n_flagged) are flagged, the rest always active
+  int a_row, d_row, n_in, n_out;
+  int w_off, b_off;      // destination offsets in a slab row
+  int P;                 // slab row length
+  int tiles_m, tiles_n;  // 16-unit tiles over outputs / inputs (+ bias column)
+  float* slab;           // [gridDim.y][P]
+};
+constexpr int DW_TM = 4, DW_TN = 4;
+__global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
+  __shared__ __attribute__((aligned(16))) float red[3 * DW_TM * DW_TN * 4 * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int bn = (d.tiles_n + DW_TN - 1) / DW_TN;
+  const int tm0 = (blockIdx.x / bn) * DW_TM, tn0 = (blockIdx.x % bn) * DW_TN;
+  f32x4 G[DW_TM][DW_TN];
+#pragma unroll
+  for (int i = 0; i < DW_TM; ++i)
+#pragma unroll
+    for (int j = 0; j < DW_TN; ++j) G[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long stride = (long long)gridDim.y * 4;
+  // operand rows of this lane: clamp to a valid row, zero the value afterwards
+  int arow[DW_TM], brow[DW_TN];
+  bool aok[DW_TM], bok[DW_TN], bone[DW_TN];
+#pragma unroll
+  for (int i = 0; i < DW_TM; ++i) {
+    const int u = 16 * (tm0 + i) + c;
+    aok[i] = u < d.n_out;
+    arow[i] = d.d_row + (aok[i] ? u : 0);
+  }
+#pragma unroll
+  for (int j = 0; j < DW_TN; ++j) {
+    const int u = 16 * (tn0 + j) + c;
+    bok[j] = u < d.n_in;
+    bone[j] = u == d.n_in;            // bias column: input = 1
+    brow[j] = d.a_row + (bok[j] ? u : 0);
+  }
+  for (long long r = (long long)blockIdx.y * 4 + wv; r < d.n_rec; r += stride) {
+    if (d.flags && r < d.n_flagged && !d.flags[r / d.flag_div]) continue;   // wave-uniform
+    const float* rec = d.rec + (size_t)r * d.rec_floats;
+    f4 af[DW_TM], bf[DW_TN];
+#pragma unroll
+    for (int i = 0; i < DW_TM; ++i) {
+      af[i] = *(const f4*)(rec + (size_t)arow[i] * 16 + 4 * g);
+      if (!aok[i]) af[i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < DW_TN; ++j) {
+      bf[j] = *(const f4*)(rec + (size_t)brow[j] * 16 + 4 * g);
+      if (!bok[j]) bf[j] = bone[j] ? f4{1.f, 1.f, 1.f, 1.f} : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < DW_TM; ++i)
+#pragma unroll
+        for (int j = 0; j < DW_TN; ++j) G[i][j] = mfma4(af[i][s], bf[j][s], G[i][j]);
+  }
+  // the four waves of the block add their tiles in fixed order -> one slab row per blockIdx.y
+  f32x4 __attribute__((address_space(3)))* rd = (f32x4 __attribute__((address_space(3)))*)(lfp)red;
+  if (wv > 0) {
+#pragma unroll
+    for (int i = 0; i < DW_TM; ++i)
+#pragma unroll
+      for (int j = 0; j < DW_TN; ++j) rd[((wv - 1) * DW_TM * DW_TN + i * DW_TN + j) * 64 + lane] = G[i][j];
+  }
+  __syncthreads();
+  if (wv != 0) return;
+  float* row = d.slab + (size_t)blockIdx.y * d.P;
+#pragma unroll
+  for (int i = 0; i < DW_TM; ++i)
+#pragma unroll
+    for (int j = 0; j < DW_TN; ++j) {
+      f32x4 t = G[i][j];
+      t += rd[(0 * DW_TM * DW_TN + i * DW_TN + j) * 64 + lane];
+      t += rd[(1 * DW_TM * DW_TN + i * DW_TN + j) * 64 + lane];
+      t += rd[(2 * DW_TM * DW_TN + i * DW_TN + j) * 64 + lane];
+      const int ui = 16 * (tn0 + j) + c;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int uo = 16 * (tm0 + i) + 4 * g + rr;
+        if (uo < d.n_out) {
+          if (ui < d.n_in) row[d.w_off + (size_t)uo * d.n_in + ui] = t[rr];
+          else if (ui == d.n_in) row[d.b_off + uo] = t[rr];
+        }
+      }
+    }
+}
+
+// ---- fragment tables ------------------------------------------------------------------------
+struct GPack { int n_layers; GLayer l[3 * GEN_MAXL]; int total; };
+__global__ void k_gen_pack(const float* __restrict__ P, float* __restrict__ frag, GPack p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.total) return;
+  for (int q = 0; q < p.n_layers; ++q) {
+    const GLayer L = p.l[q];
+    const int nf = L.MT * L.Qp * 64, nt = L.MTT * L.QTp * 64;
+    if (idx >= L.f_off && idx < L.f_off + nf) {
+      const int e = idx - L.f_off, lane = e & 63, f = e >> 6, mt = f / L.Qp, k = f % L.Qp;
+      const int o = 16 * mt + (lane & 15), i = 4 * k + (lane >> 4);
+      float v = 0.0f;
+      if (o < L.n_out) v = i < L.n_in ? P[L.w_off + (size_t)o * L.n_in + i] : (i == L.n_in ? P[L.b_off + o] : 0.0f);
+      frag[idx] = v;
+      return;
+    }
+    if (idx >= L.ft_off && idx < L.ft_off + nt) {
+      const int e = idx - L.ft_off, lane = e & 63, f = e >> 6, mt = f / L.QTp, k = f % L.QTp;
+      const int i = 16 * mt + (lane & 15), o = 4 * k + (lane >> 4);
+      frag[idx] = (i < L.n_in && o < L.n_out) ? P[L.w_off + (size_t)o * L.n_in + i] : 0.0f;
+      return;
+    }
+  }
+}
+
+// ---- plan: time index of every row, dense [time][path] -> row, first jump of every step ------
+__global__ void k_gen_rows(const int* __restrict__ time_ptr, int n_times, int n_obs,
+                           const int* __restrict__ obs_idx, int B, int* __restrict__ dense,
+                           int* __restrict__ bad) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_obs) return;
+  int lo = 0, hi = n_times;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (time_ptr[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int b = obs_idx[r];
+  if (b < 0 || b >= B) { atomicOr(bad, 1); return; }
+  dense[(size_t)lo * B + b] = r;
+}
+__global__ void k_gen_jlo(const int* __restrict__ k_jump, int n_times, int K, int* __restrict__ jlo) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > K + 1) return;
+  int lo = 0, hi = n_times;         // first i with k_jump[i] >= k
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (k_jump[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  jlo[k] = lo;
+}
+
+// grad[p] = grad_loss * sum_s slab[s][p]  (fixed order)
+__global__ void k_gen_reduce(const float* __restrict__ slab, int S, int P,
+                             const float* __restrict__ grad_loss, float* __restrict__ grad) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float acc = 0.0f;
+  for (int s = 0; s < S; ++s) acc += slab[(size_t)s * P + p];
+  grad[p] = acc * grad_loss[0];
+}
+__global__ void __launch_bounds__(1024) k_gen_sum(const float* __restrict__ x, int n, float* __restrict__ out) {
+  __shared__ float sh[1024];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += x[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+}  // namespace gen
+}  // namespace njode

@@ -1,0 +1,460 @@
+// njode_gen.hip -- host side of the shape-generic kernel family (njode_gen.h): model
+// description -> layer tables, workspace layout, plan (dense [time][path] -> row matrix, first
+// jump of every Euler step), launches.  Entry points are the gen_* functions below; the C ABI
+// (njode_api.hip) routes to them every model shape the build table has no specialisation for.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/njode_hip.h"
+#include "njode_error.h"
+#include "njode_gen.h"
+#include "njode_gen_host.h"
+
+namespace njode {
+void prof_mark(const char* name, hipStream_t st, bool begin);   // njode_api.hip
+}
+
+using namespace njode;
+using namespace njode::gen;
+
+namespace {
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  njode::set_error_v(code, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail(NJODE_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+
+struct Prof {
+  const char* name;
+  hipStream_t st;
+  Prof(const char* n, hipStream_t s) : name(n), st(s) { njode::prof_mark(name, st, true); }
+  ~Prof() { njode::prof_mark(name, st, false); }
+};
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+constexpr int LDS_LIMIT = 160 * 1024;
+
+struct Model {
+  GArgs a;          // dims and layer tables filled in; pointers null
+  int P;            // flat parameter count
+  int frag_floats;
+  int nw;           // waves per workgroup of the forward / sweep kernels
+  int lds_bytes;
+  int S;            // slab rows (K splits of the weight-gradient GEMMs)
+  GPack pack;
+};
+
+// nets of a model in the order of the flat parameter vector (state_dict order)
+bool build_net(GNet& N, int n_in, int n_out, const NjodeNet& d, int& p_off, int& f_off,
+               GPack& pack, int& img_rows, int& max_mt, int& max_tb) {
+  if (d.n_hidden < 0 || d.n_hidden > NJODE_MAX_HIDDEN) return false;
+  N.nl = d.n_hidden + 1;
+  N.n_in = n_in;
+  N.n_out = n_out;
+  int a_row = 0;
+  for (int l = 0; l < N.nl; ++l) {
+    GLayer& L = N.l[l];
+    L.n_in = l == 0 ? n_in : d.width[l - 1];
+    L.n_out = l == d.n_hidden ? n_out : d.width[l];
+    if (L.n_in <= 0 || L.n_out <= 0 || L.n_in > NJODE_GEN_MAX_WIDTH + 64 || L.n_out > NJODE_GEN_MAX_WIDTH)
+      return false;
+    L.act = l < d.n_hidden ? d.act[l] : -1;
+    if (l < d.n_hidden && L.act != NJODE_ACT_TANH && L.act != NJODE_ACT_RELU) return false;
+    L.w_off = p_off;
+    L.b_off = p_off + L.n_in * L.n_out;
+    p_off = L.b_off + L.n_out;
+    L.Qp = pad_to(cdiv(L.n_in + 1, 4), QU);
+    L.MT = cdiv(L.n_out, 16);
+    L.QTp = pad_to(cdiv(L.n_out, 4), QU);
+    L.MTT = cdiv(L.n_in, 16);
+    L.f_off = f_off;
+    f_off += L.MT * L.Qp * 64;
+    L.ft_off = f_off;
+    f_off += L.MTT * L.QTp * 64;
+    L.a_row = a_row;
+    a_row += L.n_in;
+    int need = 4 * L.Qp;
+    if (4 * L.QTp > need) need = 4 * L.QTp;
+    if (L.n_in + 1 > need) need = L.n_in + 1;
+    if (L.n_out + 1 > need) need = L.n_out + 1;
+    if (need > img_rows) img_rows = need;
+    if (L.MT > max_mt) max_mt = L.MT;
+    if (L.MTT > max_mt) max_mt = L.MTT;
+    const int tb = cdiv(L.MT, DW_TM) * cdiv(cdiv(L.n_in + 1, 16), DW_TN);
+    if (tb > max_tb) max_tb = tb;
+  }
+  int d_row = a_row;
+  for (int l = 0; l < N.nl; ++l) {
+    N.l[l].d_row = d_row;
+    d_row += N.l[l].n_out;
+  }
+  N.rec_rows = d_row;
+  for (int l = 0; l < N.nl; ++l) pack.l[pack.n_layers++] = N.l[l];
+  return true;
+}
+
+bool build_model(const NjodeDims* d, Model& m, const char** why) {
+  static const char* none = "";
+  *why = none;
+  memset(&m, 0, sizeof(m));
+  if (!d) { *why = "null dims"; return false; }
+  if (d->flags & NJODE_F_USE_RNN) { *why = "use_rnn runs on the specialised kernels only"; return false; }
+  const int D = d->input_size, H = d->hidden_size, DO = d->output_size;
+  if (D <= 0 || H <= 0 || DO <= 0 || D > 512 || H > 1024 || DO > 512) { *why = "sizes out of range"; return false; }
+  if (D != DO) { *why = "the loss compares X with the readout: input_size must equal output_size"; return false; }
+  const bool masked = d->flags & NJODE_F_MASKED, curt = d->flags & NJODE_F_INPUT_CURRENT_T,
+             res = d->flags & NJODE_F_RESIDUAL;
+  GArgs& a = m.a;
+  a.D = D; a.H = H; a.DO = DO;
+  a.masked = masked; a.curt = curt;
+  a.loss_easy = (d->flags & NJODE_F_LOSS_EASY) ? 1 : 0;
+  a.IN0 = D + H + (curt ? 3 : 2);
+  a.enc_case = a.dec_case = 0;
+  a.enc_mult = a.dec_mult = 1;
+  if (res) {   // FFNN residual rules (models.py:240-259)
+    if (D <= H) { if (H % D) { *why = "residual: output_size needs to be multiple of input_size"; return false; } a.enc_case = 1; a.enc_mult = H / D; }
+    else { if (D % H) { *why = "residual: input_size needs to be multiple of output_size"; return false; } a.enc_case = 2; a.enc_mult = D / H; }
+    if (H <= DO) { if (DO % H) { *why = "residual: output_size needs to be multiple of input_size"; return false; } a.dec_case = 1; a.dec_mult = DO / H; }
+    else { if (H % DO) { *why = "residual: input_size needs to be multiple of output_size"; return false; } a.dec_case = 2; a.dec_mult = H / DO; }
+  }
+  NjodeNet nets[3];
+  if (d->per_net) {
+    for (int i = 0; i < 3; ++i) nets[i] = d->nets[i];
+  } else {
+    if (d->n_hidden < 0 || d->n_hidden > NJODE_MAX_HIDDEN) { *why = "n_hidden out of range"; return false; }
+    for (int i = 0; i < 3; ++i) {
+      nets[i].n_hidden = d->n_hidden;
+      for (int l = 0; l < NJODE_MAX_HIDDEN; ++l) { nets[i].width[l] = d->width; nets[i].act[l] = d->act; }
+    }
+  }
+  int p_off = 0, f_off = 0, img_rows = 16, max_mt = 1, max_tb = 1;
+  m.pack.n_layers = 0;
+  if (!build_net(a.ode, a.IN0, H, nets[0], p_off, f_off, m.pack, img_rows, max_mt, max_tb) ||
+      !build_net(a.enc, masked ? 2 * D : D, H, nets[1], p_off, f_off, m.pack, img_rows, max_mt, max_tb) ||
+      !build_net(a.dec, H, DO, nets[2], p_off, f_off, m.pack, img_rows, max_mt, max_tb)) {
+    *why = "network description out of range (<= 4 hidden layers, widths <= 1024, tanh / relu)";
+    return false;
+  }
+  m.P = p_off;
+  m.frag_floats = f_off;
+  m.pack.total = f_off;
+  // the vectors the kernels stage in the images besides layer inputs: ODE input, readouts, states
+  if (a.IN0 + 4 > img_rows) img_rows = a.IN0 + 4;
+  if (2 * D + 4 > img_rows) img_rows = 2 * D + 4;
+  if (H + 4 > img_rows) img_rows = H + 4;
+  a.img_rows = pad_to(img_rows + 4, 4);
+  m.lds_bytes = gen_lds_floats(a.img_rows, D, H, DO) * 4;
+  if (m.lds_bytes > LDS_LIMIT) { *why = "layer images exceed the 160 KB LDS"; return false; }
+  m.nw = max_mt < 4 ? 4 : (max_mt > 16 ? 16 : max_mt);
+  m.S = 2048 / max_tb;
+  if (m.S < 8) m.S = 8;
+  if (m.S > 256) m.S = 256;
+  return true;
+}
+
+struct Layout {
+  size_t total = 0;
+  size_t sched, jlo, dense, bad, plan_end;
+  size_t frag, loss_terms, slab, rec_ode, rec_enc, rec_dec, ybuf, flags;
+  int T;
+  size_t take(size_t bytes) {
+    size_t off = total;
+    total += (bytes + 255) & ~(size_t)255;
+    return off;
+  }
+};
+
+Layout make_layout(const Model& m, int B, int n_obs, int nt, int K, int call_flags) {
+  Layout L;
+  L.T = cdiv(B, 16);
+  const size_t T = (size_t)L.T, ntl = (size_t)(nt > 0 ? nt : 1);
+  L.sched = L.take(((size_t)2 * K + 3 * (size_t)nt + 1) * 4 + 64);
+  L.jlo = L.take(((size_t)K + 2) * 4);
+  L.dense = L.take(ntl * (size_t)B * 4);
+  L.bad = L.take(256);
+  L.plan_end = L.total;
+  L.frag = L.take((size_t)m.frag_floats * 4);
+  L.loss_terms = L.take((size_t)B * 4);
+  if (call_flags & NJODE_C_SAVE_BWD) {
+    L.slab = L.take((size_t)m.S * m.P * 4);
+    L.rec_ode = L.take((size_t)(K > 0 ? K : 1) * T * m.a.ode.rec_rows * 64);
+    L.rec_enc = L.take(((size_t)nt * T + T) * m.a.enc.rec_rows * 64);
+    L.rec_dec = L.take(ntl * T * 2 * m.a.dec.rec_rows * 64);
+    L.ybuf = L.take(ntl * T * 2 * m.a.DO * 64);
+    L.flags = L.take(ntl * T * 4);
+  } else {
+    L.slab = L.rec_ode = L.rec_enc = L.rec_dec = L.ybuf = L.flags = 0;
+  }
+  return L;
+}
+
+int check_sizes(const NjodeBatch* b, const NjodeSchedule* s) {
+  if (!b || !s) return fail(NJODE_E_BADARG, "null argument");
+  if (b->batch_size <= 0 || b->n_obs < 0 || s->n_steps < 0 || s->n_times < 0)
+    return fail(NJODE_E_BADARG, "negative size");
+  if (!b->start_X || (b->n_obs > 0 && (!b->X || !b->obs_idx)))
+    return fail(NJODE_E_BADARG, "null batch array");
+  if ((s->n_steps > 0 && (!s->step_dt || !s->step_t)) ||
+      (s->n_times > 0 && (!s->k_jump || !s->time_f32)) || !s->time_ptr)
+    return fail(NJODE_E_BADARG, "null schedule array");
+  if ((size_t)s->n_times * (size_t)b->batch_size > ((size_t)1 << 31))
+    return fail(NJODE_E_UNSUPPORTED, "n_times x batch_size exceeds 2^31 cells");
+  return NJODE_OK;
+}
+
+// schedule copy + plan into the prefix at `pw`
+int build_plan(const Layout& L, char* pw, const NjodeBatch* b, const NjodeSchedule* s, hipStream_t st) {
+  const int K = s->n_steps, nt = s->n_times, B = b->batch_size, n = b->n_obs;
+  char* dst = pw + L.sched;
+  const size_t bdt = (size_t)K * 4, bt = (size_t)nt * 4, bp = ((size_t)nt + 1) * 4;
+  const char* h0 = (const char*)s->step_dt;
+  const bool contiguous = K > 0 && nt > 0 && (const char*)s->step_t == h0 + bdt &&
+                          (const char*)s->k_jump == h0 + 2 * bdt &&
+                          (const char*)s->time_f32 == h0 + 2 * bdt + bt &&
+                          (const char*)s->time_ptr == h0 + 2 * bdt + 2 * bt;
+  if (contiguous) {
+    HIP_TRY(hipMemcpyAsync(dst, h0, 2 * bdt + 2 * bt + bp, hipMemcpyHostToDevice, st));
+  } else {
+    if (K > 0) {
+      HIP_TRY(hipMemcpyAsync(dst, s->step_dt, bdt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(dst + bdt, s->step_t, bdt, hipMemcpyHostToDevice, st));
+    }
+    if (nt > 0) {
+      HIP_TRY(hipMemcpyAsync(dst + 2 * bdt, s->k_jump, bt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(dst + 2 * bdt + bt, s->time_f32, bt, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(dst + 2 * bdt + 2 * bt, s->time_ptr, bp, hipMemcpyHostToDevice, st));
+  }
+  const int* k_jump = (const int*)(dst + 2 * bdt);
+  const int* time_ptr = (const int*)(dst + 2 * bdt + 2 * bt);
+  int* dense = (int*)(pw + L.dense);
+  int* bad = (int*)(pw + L.bad);
+  HIP_TRY(hipMemsetAsync(bad, 0, 4, st));
+  if (nt > 0) HIP_TRY(hipMemsetAsync(dense, 0xFF, (size_t)nt * B * 4, st));
+  if (n > 0) k_gen_rows<<<cdiv(n, 256), 256, 0, st>>>(time_ptr, nt, n, b->obs_idx, B, dense, bad);
+  k_gen_jlo<<<cdiv(K + 2, 256), 256, 0, st>>>(k_jump, nt, K, (int*)(pw + L.jlo));
+  static const bool validate = getenv("NJODE_VALIDATE") && atoi(getenv("NJODE_VALIDATE")) != 0;
+  if (validate) {
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h) return fail(NJODE_E_BADARG, "obs_idx has entries outside [0, batch_size)");
+  }
+  HIP_TRY(hipGetLastError());
+  return NJODE_OK;
+}
+
+struct Call {
+  Model m;
+  Layout L;
+  GArgs a;
+};
+
+int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatch* b,
+            const NjodeSchedule* s, int call_flags, float weight, float dropout_p, uint64_t seed,
+            void* ws, size_t ws_bytes) {
+  const char* why;
+  if (!build_model(dims, c.m, &why)) return fail(NJODE_E_UNSUPPORTED, "generic kernels: %s", why);
+  int rc = check_sizes(b, s);
+  if (rc) return rc;
+  if (!params || !ws) return fail(NJODE_E_BADARG, "null argument");
+  const int B = b->batch_size, n_obs = b->n_obs, K = s->n_steps, nt = s->n_times;
+  const bool masked = (dims->flags & NJODE_F_MASKED) != 0;
+  if (masked && n_obs > 0 && !b->M) return fail(NJODE_E_BADARG, "masked model needs M");
+  if ((call_flags & NJODE_C_GET_LOSS) && !b->n_obs_ot) return fail(NJODE_E_BADARG, "get_loss needs n_obs_ot");
+  if (dropout_p < 0.0f || dropout_p >= 1.0f) return fail(NJODE_E_BADARG, "dropout_p");
+  c.L = make_layout(c.m, B, n_obs, nt, K, call_flags);
+  if (ws_bytes < c.L.total)
+    return fail(NJODE_E_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, c.L.total);
+  const bool planned = (call_flags & NJODE_C_PLAN_READY) != 0;
+  if (planned && !b->plan) return fail(NJODE_E_BADARG, "NJODE_C_PLAN_READY without NjodeBatch.plan");
+  char* w = (char*)ws;
+  char* pw = planned ? (char*)b->plan : w;
+  c.a = c.m.a;
+  GArgs& a = c.a;
+  a.P = params;
+  a.frag = (const float*)(w + c.L.frag);
+  a.B = B; a.T = c.L.T; a.n_obs = n_obs; a.K = K; a.n_times = nt;
+  a.start_X = b->start_X; a.X = b->X; a.M = b->M; a.n_obs_ot = b->n_obs_ot;
+  a.inv_batch = 1.0f / b->loss_batch_size;
+  a.gid0 = (unsigned long long)b->path_id_offset;
+  const float* sb = (const float*)(pw + c.L.sched);
+  a.step_dt = sb;
+  a.step_t = sb + K;
+  a.time_f32 = sb + 2 * (size_t)K + nt;
+  a.jlo = (const int*)(pw + c.L.jlo);
+  a.dense = (const int*)(pw + c.L.dense);
+  a.loss_terms = (float*)(w + c.L.loss_terms);
+  a.save = (call_flags & NJODE_C_SAVE_BWD) ? 1 : 0;
+  if (a.save) {
+    a.rec_ode = (float*)(w + c.L.rec_ode);
+    a.rec_enc = (float*)(w + c.L.rec_enc);
+    a.rec_dec = (float*)(w + c.L.rec_dec);
+    a.ybuf = (float*)(w + c.L.ybuf);
+    a.flags = (int*)(w + c.L.flags);
+  }
+  a.want_loss = (call_flags & NJODE_C_GET_LOSS) ? 1 : 0;
+  a.want_path = (call_flags & NJODE_C_RETURN_PATH) ? 1 : 0;
+  const bool any_hidden = c.m.a.ode.nl > 1 || c.m.a.enc.nl > 1 || c.m.a.dec.nl > 1;
+  a.drop = ((call_flags & NJODE_C_TRAIN) && dropout_p > 0.0f && any_hidden) ? 1 : 0;
+  unsigned thr = (unsigned)(dropout_p * 65536.0f + 0.5f);
+  if (thr > 65535u) thr = 65535u;
+  a.dc.seed_lo = (uint32_t)seed;
+  a.dc.seed_hi = (uint32_t)(seed >> 32);
+  a.dc.thr16 = a.drop ? thr : 0;
+  a.keep = 1.0f - (float)a.dc.thr16 / 65536.0f;
+  a.dc.inv_keep = 1.0f / a.keep;
+  a.weight = weight;
+  return NJODE_OK;
+}
+
+int set_lds(const void* fn, int bytes) {
+  if (bytes > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return NJODE_OK;
+}
+
+}  // namespace
+
+namespace njode {
+namespace gen {
+
+bool gen_supported(const NjodeDims* dims) {
+  Model m;
+  const char* why;
+  return build_model(dims, m, &why);
+}
+
+size_t gen_param_count(const NjodeDims* dims) {
+  Model m;
+  const char* why;
+  return build_model(dims, m, &why) ? (size_t)m.P : 0;
+}
+
+int gen_workspace_bytes(const NjodeDims* dims, int B, int n_obs, int nt, int K, int call_flags,
+                        size_t* out, bool plan_only) {
+  Model m;
+  const char* why;
+  if (!build_model(dims, m, &why)) return fail(NJODE_E_UNSUPPORTED, "generic kernels: %s", why);
+  if (!out || B <= 0 || n_obs < 0 || nt < 0 || K < 0) return fail(NJODE_E_BADARG, "bad size");
+  const Layout L = make_layout(m, B, n_obs, nt, K, call_flags);
+  *out = plan_only ? L.plan_end : L.total;
+  return NJODE_OK;
+}
+
+int gen_plan(const NjodeDims* dims, const NjodeBatch* b, const NjodeSchedule* s, int call_flags,
+             void* plan, size_t plan_bytes, hipStream_t st) {
+  Model m;
+  const char* why;
+  if (!build_model(dims, m, &why)) return fail(NJODE_E_UNSUPPORTED, "generic kernels: %s", why);
+  int rc = check_sizes(b, s);
+  if (rc) return rc;
+  if (!plan) return fail(NJODE_E_BADARG, "null plan buffer");
+  const Layout L = make_layout(m, b->batch_size, b->n_obs, s->n_times, s->n_steps, call_flags);
+  if (plan_bytes < L.plan_end) return fail(NJODE_E_WORKSPACE, "plan buffer too small: %zu < %zu", plan_bytes, L.plan_end);
+  return build_plan(L, (char*)plan, b, s, st);
+}
+
+int gen_forward(const NjodeDims* dims, const float* params, const NjodeBatch* b,
+                const NjodeSchedule* s, int call_flags, float weight, float dropout_p,
+                uint64_t seed, float* hT, float* loss, float* path_h, float* path_y, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+  Call c;
+  int rc = prepare(c, dims, params, b, s, call_flags, weight, dropout_p, seed, ws, ws_bytes);
+  if (rc) return rc;
+  const bool want_loss = call_flags & NJODE_C_GET_LOSS, want_path = call_flags & NJODE_C_RETURN_PATH;
+  if ((want_loss && !loss) || (want_path && (!path_h || !path_y))) return fail(NJODE_E_BADARG, "null output");
+  if ((call_flags & NJODE_C_SAVE_BWD) && !want_loss) return fail(NJODE_E_BADARG, "NJODE_C_SAVE_BWD needs NJODE_C_GET_LOSS");
+  c.a.hT = hT;
+  c.a.path_h = path_h;
+  c.a.path_y = path_y;
+  if (!(call_flags & NJODE_C_PLAN_READY)) {
+    if ((rc = build_plan(c.L, (char*)ws, b, s, st))) return rc;
+  }
+  {
+    Prof ps("k_gen_pack", st);
+    k_gen_pack<<<cdiv(c.m.pack.total, 256), 256, 0, st>>>(params, (float*)c.a.frag, c.m.pack);
+  }
+  if (c.a.save) HIP_TRY(hipMemsetAsync(c.a.flags, 0, (size_t)(s->n_times > 0 ? s->n_times : 1) * c.L.T * 4, st));
+  if ((rc = set_lds((const void*)k_gen_fwd, c.m.lds_bytes))) return rc;
+  {
+    Prof ps("k_gen_fwd", st);
+    k_gen_fwd<<<c.L.T, c.m.nw * 64, c.m.lds_bytes, st>>>(c.a);
+  }
+  if (want_loss) k_gen_sum<<<1, 1024, 0, st>>>(c.a.loss_terms, b->batch_size, loss);
+  HIP_TRY(hipGetLastError());
+  return NJODE_OK;
+}
+
+int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b,
+                 const NjodeSchedule* s, int call_flags, float weight, float dropout_p,
+                 uint64_t seed, const float* grad_loss, float* grad_params, void* ws,
+                 size_t ws_bytes, hipStream_t st) {
+  Call c;
+  int rc = prepare(c, dims, params, b, s, call_flags, weight, dropout_p, seed, ws, ws_bytes);
+  if (rc) return rc;
+  if (!grad_loss || !grad_params) return fail(NJODE_E_BADARG, "null gradient pointer");
+  if (!(call_flags & NJODE_C_SAVE_BWD) || !(call_flags & NJODE_C_GET_LOSS))
+    return fail(NJODE_E_BADARG, "backward needs a forward with NJODE_C_SAVE_BWD | NJODE_C_GET_LOSS");
+  // (schedule copy, plan, fragment tables and records are where the forward left them)
+  if ((rc = set_lds((const void*)k_gen_bwd, c.m.lds_bytes))) return rc;
+  {
+    Prof ps("k_gen_bwd", st);
+    k_gen_bwd<<<c.L.T, c.m.nw * 64, c.m.lds_bytes, st>>>(c.a);
+  }
+  float* slab = (float*)((char*)ws + c.L.slab);
+  const GArgs& a = c.a;
+  const long long T = c.L.T, nt = a.n_times;
+  auto dw = [&](const GNet& N, const float* rec, long long n_rec, const int* flags, int flag_div,
+                long long n_flagged) {
+    for (int l = 0; l < N.nl; ++l) {
+      const GLayer& Ly = N.l[l];
+      GDw d;
+      d.rec = rec;
+      d.n_rec = n_rec;
+      d.rec_floats = N.rec_rows * 16;
+      d.flags = flags;
+      d.flag_div = flag_div;
+      d.n_flagged = n_flagged;
+      d.a_row = Ly.a_row;
+      d.d_row = Ly.d_row;
+      d.n_in = Ly.n_in;
+      d.n_out = Ly.n_out;
+      d.w_off = Ly.w_off;
+      d.b_off = Ly.b_off;
+      d.P = c.m.P;
+      d.tiles_m = Ly.MT;
+      d.tiles_n = cdiv(Ly.n_in + 1, 16);
+      d.slab = slab;
+      const int tb = cdiv(d.tiles_m, DW_TM) * cdiv(d.tiles_n, DW_TN);
+      k_gen_dw<<<dim3(tb, c.m.S), 256, 0, st>>>(d);
+    }
+  };
+  {
+    Prof ps("k_gen_dw", st);
+    dw(a.ode, a.rec_ode, (long long)a.K * T, nullptr, 1, 0);
+    dw(a.enc, a.rec_enc, nt * T + T, a.flags, 1, nt * T);
+    dw(a.dec, a.rec_dec, nt * T * 2, a.flags, 2, nt * T * 2);
+  }
+  k_gen_reduce<<<cdiv(c.m.P, 256), 256, 0, st>>>(slab, c.m.S, c.m.P, grad_loss, grad_params);
+  HIP_TRY(hipGetLastError());
+  return NJODE_OK;
+}
+
+}  // namespace gen
+}  // namespace njode

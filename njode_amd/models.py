@@ -237,17 +237,15 @@ class _NJODEFunction(torch.autograd.Function):
 # the model
 # =====================================================================================
 def _desc_of(nn_desc):
-    """(n_hidden, width, act) if the description fits the kernel family, else None."""
+    """(n_hidden, widths, acts) of a get_ffnn description (``nn_desc=None``: one Linear)."""
     if nn_desc is None:
-        return (0, 0, _lib.ACT_TANH)
-    widths = {int(w) for w, _ in nn_desc}
-    acts = {a for _, a in nn_desc}
-    if len(widths) != 1 or len(acts) != 1 or len(nn_desc) > 2:
-        return None
-    act = acts.pop()
-    if act not in nonlinears:
-        raise KeyError(act)
-    return (len(nn_desc), widths.pop(), _lib.ACT_TANH if act == 'tanh' else _lib.ACT_RELU)
+        return (0, (), ())
+    widths = tuple(int(w) for w, _ in nn_desc)
+    for _, a in nn_desc:
+        if a not in nonlinears:
+            raise KeyError(a)
+    acts = tuple(_lib.ACT_TANH if a == 'tanh' else _lib.ACT_RELU for _, a in nn_desc)
+    return (len(nn_desc), widths, acts)
 
 
 class NJODE(torch.nn.Module):
@@ -412,28 +410,42 @@ class NJODE(torch.nn.Module):
                                       '(models.py:353 TODO)')
         if self.solver != 'euler':
             raise ValueError("Unknown solver '{}'.".format(self.solver))
-        if None in self._descs or len(set(self._descs)) != 1:
-            raise NotImplementedError(
-                'the gfx950 kernels are specialised for three networks with the same '
-                'hidden structure (<= 2 hidden layers of one width and activation); got '
-                'ode/enc/readout = {}'.format(self._descs))
-        nh, width, act = self._descs[0]
         flags = ((_lib.F_MASKED if self.masked else 0)
                  | (_lib.F_INPUT_CURRENT_T if self.input_current_t else 0)
                  | (_lib.F_RESIDUAL if self.residual_enc_dec else 0)
                  | (_lib.F_LOSS_EASY if self.which_loss == 'easy' else 0)
                  | (_lib.F_USE_RNN if self.use_rnn else 0))
-        d = _lib.NjodeDims(self.input_size, self.hidden_size, self.output_size, nh, width,
-                           act, flags)
+        nh, widths, acts = self._descs[0]
+        uniform = (len(set(self._descs)) == 1 and len(set(widths)) <= 1 and len(set(acts)) <= 1)
+        if uniform:
+            # the three networks share one hidden structure (every configuration of the
+            # reference's own scripts): the compact description, which the shape-specialised
+            # kernels of the build table are keyed by
+            d = _lib.NjodeDims(self.input_size, self.hidden_size, self.output_size, nh,
+                               widths[0] if nh else 0, acts[0] if nh else _lib.ACT_TANH, flags)
+        else:
+            # per-network descriptions (shape-generic kernels)
+            d = _lib.NjodeDims(self.input_size, self.hidden_size, self.output_size, 0, 0, 0, flags)
+            d.per_net = 1
+            for i, (n, ws, as_) in enumerate(self._descs):
+                if n > _lib.MAX_HIDDEN:
+                    raise NotImplementedError(
+                        'libnjode_hip.so runs networks with up to {} hidden layers; got {}'
+                        .format(_lib.MAX_HIDDEN, n))
+                d.nets[i].n_hidden = n
+                for l in range(n):
+                    d.nets[i].width[l] = ws[l]
+                    d.nets[i].act[l] = as_[l]
         if not _lib.lib().njode_supported(ctypes.byref(d)):
             raise NotImplementedError(
-                'libnjode_hip.so has no gfx950 specialisation for input_size={}, '
-                'hidden_size={}, output_size={}, n_hidden={}, width={}, act={}, masked={}, '
-                'input_current_t={}, residual={}, use_rnn={}.  Add the shape to CONFIGS in '
-                'njode_amd/build.py (or NJODE_EXTRA_CONFIGS) and rebuild.  Compiled: {}'
-                .format(self.input_size, self.hidden_size, self.output_size, nh, width,
-                        act, self.masked, self.input_current_t, self.residual_enc_dec,
-                        self.use_rnn, _lib.build_info()))
+                'libnjode_hip.so has no gfx950 kernels for input_size={}, hidden_size={}, '
+                'output_size={}, ode/enc/readout nets (n_hidden, widths, acts)={}, masked={}, '
+                'input_current_t={}, residual={}, use_rnn={} (the shape-generic kernels run '
+                'every model without use_rnn whose widths are <= {}; use_rnn needs an entry of '
+                'CONFIGS in njode_amd/build.py).  {}'
+                .format(self.input_size, self.hidden_size, self.output_size, self._descs,
+                        self.masked, self.input_current_t, self.residual_enc_dec,
+                        self.use_rnn, 1024, _lib.build_info()))
         self._dims = d
         return d
 

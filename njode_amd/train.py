@@ -69,7 +69,8 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
           weight_decay=1., test_size=0.2, seed=398, device='cuda', fused=True,
           evaluate=False, shuffle_seed=0, log=print, max_steps_per_epoch=None,
           device_collate=False, model_path=None, model_id=1, save_every=1,
-          resume_training=False, load_best=False, plan_ahead=True, **options):
+          resume_training=False, load_best=False, plan_ahead=True, plan_ahead_min=0,
+          **options):
     """Train on an in-memory dataset ``(stock_paths, observed_dates, nb_obs)`` with
     ``metadata`` as returned by ``data_utils.create_dataset``.  Returns
     ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch.
@@ -193,9 +194,10 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             # one batch ahead: the next batch is collated now, and (fused loop) its execution
             # plan is built on a helper stream beside this step (NJODE.prefetch_plan)
             nxt = prepare(s + 1) if s + 1 < n_steps else None
-            # (only where the GPU step is long against the host's per-step work: at B = 100 the loop
-            # is host-bound and the extra call costs 15 %, profiles/r02_producer_bench.jsonl)
-            if plan_ahead and fused and nxt is not None and len(nxt[2]) >= 4096:
+            # (``plan_ahead_min``: smallest local batch that is planned ahead.  Round 2 used 4 096 --
+            # the loop was host-bound below that; with one host round trip per EPOCH in the device
+            # collate the host has slack at every batch size, profiles/r03_harness_epochs.jsonl)
+            if plan_ahead and fused and nxt is not None and len(nxt[2]) >= max(plan_ahead_min, 1):
                 dn = nxt[3]
                 if dn.get('ready') is not None:
                     torch.cuda.current_stream().wait_event(dn['ready'])

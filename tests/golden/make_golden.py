@@ -24,6 +24,11 @@ Cases:
                           stand-in: observe the first half, predict the second half
   g9_ref_training_curves  (round 3) the shipped metric_id-{1,2,3}.csv columns: what a training
                           run has to track
+  g8_climate_eval (g11, round 3)  climate_train.evaluate_model protocol (:508-566) on a synthetic
+                          stand-in: observe up to T_val, predict the held-out measurements
+  g10 (round 3): g6_w100, g6_none_h50, g6_mixed_nets, g5_w200, g5_climate -- shapes that run on
+                          the shape-generic kernels (widths >= 64, nn_desc = None with H = 50,
+                          per-network descriptions, the climate shape)
 """
 import contextlib
 import copy
@@ -447,8 +452,103 @@ def g9():
     save('g9_ref_training_curves', json.loads(desc), arrays)
 
 
+def g10():
+    """Shapes of the reference's grids that only the shape-generic kernels run (round 3):
+    width 100 (parallel_train.py:609), PhysioNet width 200 (:650, masked d = H = 41),
+    nn_desc = None with hidden_size 50 (:366-371), the climate shape d = 5, H = 10 masked
+    (:433-448; residual cases 1 with mult 2 and 2 with mult 2), and one model whose three
+    networks differ (3 hidden layers of different widths / activations, one hidden layer, none)."""
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    dt, T = hp['dt'], hp['maturity']
+    nn100 = ((100, 'tanh'), (100, 'tanh'))
+    cases = {
+        'g6_w100': (dict(demo_cfg(dropout=0.0), ode_nn=nn100, enc_nn=nn100, readout_nn=nn100), 20, None),
+        'g6_none_h50': (dict(demo_cfg(H=50, dropout=0.0), ode_nn=None, enc_nn=None, readout_nn=None), 20, None),
+        'g6_mixed_nets': (dict(demo_cfg(d=2, dropout=0.0, input_current_t=True),
+                               ode_nn=((64, 'tanh'), (32, 'relu'), (48, 'tanh')),
+                               enc_nn=((30, 'relu'),), readout_nn=None), 18, ['power-2']),
+    }
+    for name, (cfg, B, funcs) in cases.items():
+        model = build(cfg)
+        b = ref_collate(paths, obs, nb_obs, dt, range(B), funcs)
+        arrays = {**sd_arrays(model), **batch_arrays(b), 'delta_t': dt, 'T': T}
+        arrays.update(eval_outputs(model, b, dt, T))
+        arrays.update(grad_outputs(model, b, dt, T))
+        save(name, cfg, arrays)
+    nn200 = ((200, 'tanh'), (200, 'tanh'))
+    masked = {
+        'g5_w200': (dict(input_size=41, hidden_size=41, output_size=41, ode_nn=nn200, readout_nn=nn200,
+                         enc_nn=nn200, use_rnn=False, bias=True, dropout_rate=0.0,
+                         options={'masked': True}),
+                    synthetic_physionet.make_batch(batch_size=5, n_grid=60, n_obs_range=(4, 10), seed=2)),
+        'g5_climate': (dict(input_size=5, hidden_size=10, output_size=5, ode_nn=NN, readout_nn=NN,
+                            enc_nn=NN, use_rnn=False, bias=True, dropout_rate=0.0,
+                            options={'masked': True}),
+                       synthetic_physionet.make_batch(batch_size=19, dim=5, n_grid=80, n_obs_range=(4, 12),
+                                                      p_feature=0.4, seed=5)),
+    }
+    for name, (cfg, b) in masked.items():
+        model = build(cfg)
+        arrays = {**sd_arrays(model), **batch_arrays(b, with_M=True), 'delta_t': b['delta_t'], 'T': b['T']}
+        out = eval_outputs(model, b, b['delta_t'], b['T'], M=b['M'])
+        out.pop('path_h')
+        arrays.update(out)
+        arrays.update(grad_outputs(model, b, b['delta_t'], b['T'], M=b['M']))
+        save(name, cfg, arrays)
+
+
+def _reference_climate_functions():
+    """evaluate_model of NJODE/climate_train.py executed from the reference's own source (the
+    module cannot be imported: telegram / sklearn-side imports), with the reference's
+    GRU_ODE_Bayes.data_utils_gru_ode_bayes (extract_from_path) imported as it is."""
+    import ast
+    if not hasattr(np, 'int'):
+        np.int = int            # the reference predates numpy 1.24
+    import GRU_ODE_Bayes.data_utils_gru_ode_bayes as data_utils_gru
+    src = open('/root/reference/NJODE/climate_train.py').read()
+    keep = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'evaluate_model']
+    ns = {'np': np, 'torch': torch, 'data_utils_gru': data_utils_gru}
+    exec(compile(ast.Module(keep, []), 'climate_train.py', 'exec'), ns)
+    return ns['evaluate_model'], data_utils_gru.extract_from_path
+
+
+def g11():
+    """Climate evaluation protocol (climate_train.py:508-566) on the synthetic stand-in of
+    njode_amd/climate_eval.py: the reference's (loss_val, mse_val) and, per batch, what its
+    extract_from_path returns."""
+    from njode_amd import climate_eval
+    evaluate_model, extract = _reference_climate_functions()
+    cfg = dict(input_size=5, hidden_size=10, output_size=5, ode_nn=NN, readout_nn=NN, enc_nn=NN,
+               use_rnn=False, bias=True, dropout_rate=0.0, options={'masked': True})
+    model = build(cfg)
+    batches = [climate_eval.make_climate_batch(batch_size=7, T=20, T_val=15, n_obs_range=(5, 12), seed=s)
+               for s in (1, 2)]
+    dt, T = batches[0]['delta_t'], batches[0]['T']
+    ref_batches = [dict(b, times_val=b['times_val'].copy()) for b in batches]   # (the reference edits times_val in place)
+    loss_val, mse_val = quiet(evaluate_model, model, ref_batches, 'cpu', {}, dt, T)
+    arrays = {**sd_arrays(model), 'delta_t': dt, 'T': T, 'n_batches': len(batches),
+              'loss_val': np.float64(loss_val), 'mse_val': np.float64(mse_val)}
+    for i, b in enumerate(batches):
+        for k in ('times', 'time_ptr', 'times_val', 'index_val'):
+            arrays['b{}/{}'.format(i, k)] = np.asarray(b[k])
+        for k in ('X', 'M', 'obs_idx', 'X_val', 'M_val'):
+            arrays['b{}/{}'.format(i, k)] = b[k].numpy()
+        arrays['b{}/batch_size'.format(i)] = len(b['pat_idx'])
+        model.eval()
+        with torch.no_grad():
+            n_obs_ot = torch.tensor(np.bincount(b['obs_idx'].numpy(), minlength=len(b['pat_idx'])))
+            _, _, path_t, _, path_y = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt, T,
+                                            torch.zeros(len(b['pat_idx']), 5), n_obs_ot, until_T=True,
+                                            return_path=True, get_loss=True, M=b['M'])
+        t_vec = np.around(path_t, 1).astype(np.float32)
+        arrays['b{}/path_t'.format(i)] = np.asarray(path_t, dtype=np.float64)
+        arrays['b{}/p_val'.format(i)] = extract(t_vec, path_y, b['times_val'].copy(), b['index_val']).numpy()
+    print('    climate eval protocol:', loss_val, mse_val)
+    save('g8_climate_eval', cfg, arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
     for name in which:
         globals()[name]()

@@ -1,0 +1,218 @@
+"""The shape-generic matrix-core kernels (njode_amd/csrc/njode_gen.h): every model shape the
+build table has no specialisation for -- widths >= 64, nn_desc=None with wide hidden states,
+networks that differ from each other, deeper networks, the climate shape.
+
+* NJODE_GENERIC=1 routes EVERY model without a GRU jump to them: the whole parity suite (all
+  reference goldens: eval paths, losses, gradients, Adam steps, masked configs incl. the
+  3 000-step one) is re-run that way in a child process;
+* shapes of the reference's grids beyond the goldens against the CPU oracle;
+* dropout: gradient against central finite differences, mean loss against the oracle's;
+* ragged tiles, no observations, data-parallel shards."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from hip_util import (ATOL, GRAD_REL_L2, LOSS_RTOL, RTOL, bs_batch, grads_by_name, hip_forward,
+                      hip_model, oracle_forward, rel_l2, to_dev)
+from njode_amd import synthetic_physionet
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(2400)
+def test_parity_suite_on_the_generic_kernels():
+    env = dict(os.environ, NJODE_GENERIC='1')
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(REPO, 'tests', 'test_hip_parity.py'),
+           os.path.join(REPO, 'tests', 'test_hip_masked_return_path.py'),
+           '-m', 'gpu', '-q', '-x', '--timeout', '900', '-p', 'no:cacheprovider']
+    p = subprocess.run(cmd, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    assert p.returncode == 0, p.stdout[-6000:]
+
+
+def _cfg(d, H, ode, enc, dec, dropout=0.0, **options):
+    return dict(input_size=d, hidden_size=H, output_size=d, ode_nn=ode, readout_nn=dec, enc_nn=enc,
+                use_rnn=False, bias=True, dropout_rate=dropout, options=options)
+
+
+def _w(n, act='tanh', layers=2):
+    return tuple((n, act) for _ in range(layers))
+
+
+UNMASKED = {
+    # convergence study / sine / width-400 grids (parallel_train.py:304-305, 609, 712)
+    'w80': (_cfg(1, 10, _w(80), _w(80), _w(80)), 37),
+    'w160': (_cfg(1, 10, _w(160), _w(160), _w(160)), 21),
+    'w400': (_cfg(1, 10, _w(400), _w(400), _w(400)), 17),
+    # nn_desc = None with hidden_size 100 (parallel_train.py:366-371)
+    'none_h100': (_cfg(1, 100, None, None, None), 33),
+    # four hidden layers, relu; no residual; one-layer nets
+    'deep_relu': (_cfg(1, 12, _w(24, 'relu', 4), _w(24, 'relu', 4), _w(24, 'relu', 4),
+                       residual_enc_dec=False), 40),
+    'one_layer_easy': (_cfg(2, 6, _w(70, 'tanh', 1), _w(18, 'relu', 1), _w(65, 'tanh', 1),
+                            which_loss='easy'), 23),
+}
+
+
+@pytest.mark.parametrize('name', sorted(UNMASKED))
+def test_unmasked_shapes_against_the_oracle(name):
+    cfg, B = UNMASKED[name]
+    torch.manual_seed(3)
+    m = hip_model(cfg).train()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    b, meta = bs_batch(B, seed=7)
+    if cfg['input_size'] == 2:
+        b['X'] = torch.cat([b['X'], b['X'] ** 2], 1)
+        b['start_X'] = torch.cat([b['start_X'], b['start_X'] ** 2], 1)
+    dt, T = meta['dt'], meta['maturity']
+    (h_o, l_o), params = oracle_forward(cfg, sd, b, dt, T, grads=True)
+    l_o.backward()
+    hT, loss = hip_forward(m, b, dt, T)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+    np.testing.assert_allclose(hT.detach().cpu().numpy(), h_o.detach().numpy(), atol=ATOL, rtol=RTOL)
+    got = grads_by_name(m)
+    for k, p in params.items():
+        assert rel_l2(got[k], p.grad.numpy()) < GRAD_REL_L2, (k, rel_l2(got[k], p.grad.numpy()))
+    # prediction path with the until_T tail, eval mode
+    m.eval()
+    with torch.no_grad():
+        hT2, loss2, path_t, path_h, path_y = hip_forward(m, b, dt, T + 0.03, return_path=True,
+                                                         get_loss=True, until_T=True)
+        (h2, l2, pt, ph, py), _ = oracle_forward(cfg, sd, b, dt, T + 0.03, return_path=True,
+                                                 until_T=True)
+    assert np.array_equal(path_t, pt)
+    np.testing.assert_allclose(path_y.cpu().numpy(), py.numpy(), atol=ATOL, rtol=RTOL)
+    np.testing.assert_allclose(path_h.cpu().numpy(), ph.numpy(), atol=ATOL, rtol=RTOL)
+    assert float(loss2) == pytest.approx(float(l2), rel=LOSS_RTOL)
+
+
+def _masked_batch(dim, B, seed):
+    return synthetic_physionet.make_batch(batch_size=B, dim=dim, n_grid=90, n_obs_range=(3, 11),
+                                          p_feature=0.3, seed=seed)
+
+
+MASKED = {
+    # climate grids (parallel_train.py:433-470): d = 5, H = 10 / 50, widths 50 / 400
+    'climate_w400_h50': (_cfg(5, 50, _w(400), _w(400), _w(400), masked=True), 9),
+    # PhysioNet H = 50 non-residual (BASELINE config 5 wording) at width 100
+    'physio_h50_w100': (_cfg(41, 50, _w(100), _w(100), _w(100), masked=True,
+                             residual_enc_dec=False), 6),
+    # residual case 2 in the encoder (input larger than the hidden state)
+    'd8_h4': (_cfg(8, 4, _w(20), _w(33, 'relu', 1), None, masked=True), 21),
+}
+
+
+@pytest.mark.parametrize('name', sorted(MASKED))
+def test_masked_shapes_against_the_oracle(name):
+    cfg, B = MASKED[name]
+    torch.manual_seed(5)
+    m = hip_model(cfg).train()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    b = _masked_batch(cfg['input_size'], B, seed=4)
+    dt, T = b['delta_t'], b['T']
+    (h_o, l_o), params = oracle_forward(cfg, sd, b, dt, T, grads=True)
+    l_o.backward()
+    hT, loss = hip_forward(m, b, dt, T)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+    np.testing.assert_allclose(hT.detach().cpu().numpy(), h_o.detach().numpy(), atol=2e-5, rtol=RTOL)
+    got = grads_by_name(m)
+    for k, p in params.items():
+        assert rel_l2(got[k], p.grad.numpy()) < GRAD_REL_L2, (k, rel_l2(got[k], p.grad.numpy()))
+
+
+def _args(b, dt, T):
+    d = to_dev(b)
+    return (d['times'], d['time_ptr'], d['X'], d['obs_idx'], dt, T, d['start_X'], d['n_obs_ot'])
+
+
+def test_generic_dropout_gradient_matches_finite_differences():
+    cfg = _cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1)
+    b, meta = bs_batch(200, seed=6)
+    torch.manual_seed(0)
+    m = hip_model(cfg).train()
+    args = _args(b, meta['dt'], meta['maturity'])
+    m._step_counter = 3
+    _, loss = m.loss_and_grad(*args)
+    g = m.flat_grad().clone()
+    flat = m.flat_parameters()
+    v = torch.randn_like(flat)
+    v /= v.norm()
+    base = flat.clone()
+    eps = 2e-2
+    vals = []
+    for s in (+1, -1):
+        flat.copy_(base + s * eps * v)
+        m._step_counter = 3
+        with torch.no_grad():
+            vals.append(float(m(*args)[1].double()))
+    flat.copy_(base)
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    an = float((g * v).sum())
+    assert fd == pytest.approx(an, rel=3e-2, abs=1e-4)
+    # deterministic per (seed, step), different across steps, off in eval mode
+    m._step_counter = 3
+    with torch.no_grad():
+        l3 = float(m(*args)[1])
+        l4 = float(m(*args)[1])
+    assert l3 == pytest.approx(float(loss), rel=1e-6) and l4 != l3
+
+
+def test_generic_dropout_loss_distribution_matches_oracle():
+    cfg = _cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1)
+    b, meta = bs_batch(96, seed=4)
+    torch.manual_seed(0)
+    m = hip_model(cfg).train()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    n = 150
+    with torch.no_grad():
+        hip = np.array([float(hip_forward(m, b, meta['dt'], meta['maturity'])[1]) for _ in range(n)])
+    torch.manual_seed(123)
+    ora = []
+    with torch.no_grad():
+        for _ in range(n):
+            (_, l), _ = oracle_forward(cfg, sd, b, meta['dt'], meta['maturity'], training=True)
+            ora.append(float(l))
+    ora = np.array(ora)
+    se = np.sqrt(hip.var(ddof=1) / n + ora.var(ddof=1) / n)
+    assert abs(hip.mean() - ora.mean()) < 4 * se, (hip.mean(), ora.mean(), se)
+    assert 0.5 < hip.std() / ora.std() < 2.0
+
+
+def test_generic_shards_add_up_and_edge_cases():
+    cfg = _cfg(1, 10, _w(100), _w(100), _w(100))
+    torch.manual_seed(1)
+    m = hip_model(cfg).train()
+    b, meta = bs_batch(83, seed=9)           # 6 tiles, the last one with 3 paths
+    dt, T = meta['dt'], meta['maturity']
+    from njode_amd import data_utils
+    _, loss = m.loss_and_grad(*_args(b, dt, T))
+    g_full = m.flat_grad().clone()
+    total, g_sum = 0.0, torch.zeros_like(g_full)
+    for lo, hi in ((0, 1), (1, 30), (30, 83)):
+        idx = np.arange(lo, hi)
+        bs = data_utils.collate_arrays(b['true_paths'][idx], b['observed_dates'][idx],
+                                       b['observed_dates'][idx][:, 1:].sum(1), dt)
+        m.dp_global_batch, m.dp_path_offset = 83, lo
+        _, l = m.loss_and_grad(*_args(bs, dt, T))
+        total += float(l)
+        g_sum += m.flat_grad()
+    m.dp_global_batch, m.dp_path_offset = None, 0
+    assert total == pytest.approx(float(loss), rel=2e-5)
+    assert rel_l2(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 1e-4
+    # nobody observed: loss 0, zero gradient except nothing; hT = encoder(start_X) evolved
+    empty = dict(b, times=np.zeros(0), time_ptr=np.zeros(1, dtype=np.int64), X=torch.zeros(0, 1),
+                 obs_idx=torch.zeros(0, dtype=torch.long), n_obs_ot=torch.zeros(83, dtype=torch.long))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    m.eval()
+    with torch.no_grad():
+        hT, loss0 = hip_forward(m, empty, dt, T, until_T=True)
+        (h_o, _), _ = oracle_forward(cfg, sd, empty, dt, T, get_loss=False, until_T=True)
+    assert float(loss0) == 0.0
+    np.testing.assert_allclose(hT.cpu().numpy(), h_o.numpy(), atol=ATOL, rtol=RTOL)

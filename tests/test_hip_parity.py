@@ -185,7 +185,7 @@ def test_larger_batch_loss_and_grads_vs_oracle(n_paths):
     np.testing.assert_allclose(hT2.cpu().numpy(), h_o.detach().numpy(), atol=ATOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize('name', ['g5_masked', 'g5_full'])
+@pytest.mark.parametrize('name', ['g5_masked', 'g5_full', 'g5_w200', 'g5_climate'])
 def test_masked_gradients_match_reference(name):
     """BASELINE config 5 shape (PhysioNet-like, d = 41, masked, self-imputation): the
     lockstep backward (adjoint sweep + parallel weight-gradient kernels) against the
@@ -225,10 +225,16 @@ def test_lockstep_backward_matches_reference_on_unmasked_models(name):
 
 
 def test_unsupported_shape_fails_loudly():
+    """The GRU jump exists for the shapes of the build table only (the shape-generic kernels run
+    everything else without use_rnn): any other GRU shape raises instead of computing something."""
     nn = ((33, 'tanh'), (33, 'tanh'))
-    m = models.NJODE(1, 10, 1, nn, nn, nn, use_rnn=False, options={}).cuda()
+    m = models.NJODE(1, 10, 1, nn, nn, nn, use_rnn=True, options={}).cuda()
     b, meta = bs_batch(8)
-    with pytest.raises(NotImplementedError, match='no gfx950 specialisation'):
+    with pytest.raises(NotImplementedError, match='no gfx950 kernels'):
+        hip_forward(m, b, meta['dt'], meta['maturity'])
+    nn5 = tuple((12, 'tanh') for _ in range(5))     # more hidden layers than the library takes
+    m = models.NJODE(1, 10, 1, nn5, nn5, nn5, use_rnn=False, options={}).cuda()
+    with pytest.raises(NotImplementedError):
         hip_forward(m, b, meta['dt'], meta['maturity'])
 
 

@@ -22,14 +22,14 @@ def main():
     opt = models.FusedAdam(model, lr=1e-3, weight_decay=0.0005)
     for B in sizes:
         row = {'case': 'epoch', 'train_paths': 16000, 'batch': B}
-        for dc in (False, True):
+        for dc, pa in ((False, 0), (True, 0), (True, 1 << 30)):
             best = None
             for rep in range(3):
                 with contextlib.redirect_stdout(sys.stderr):
                     _, met = train.train((paths, obs, nb_obs), meta, epochs=1, batch_size=B,
-                                         log=lambda s: None, device_collate=dc)
+                                         log=lambda s: None, device_collate=dc, plan_ahead_min=pa)
                 best = met[0][1] if best is None else min(best, met[0][1])
-            key = 'device_collate' if dc else 'host_collate'
+            key = ('device_collate' if dc else 'host_collate') + ('_inline_plan' if pa else '')
             n_steps = (16000 + B - 1) // B
             row[key + '_ms_per_step'] = round(best * 1e3 / n_steps, 4)
             row[key + '_paths_per_s'] = round(16000 / best, 1)
