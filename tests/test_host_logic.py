@@ -228,15 +228,34 @@ def test_library_loads_and_exports_declared_symbols():
     d = _lib.NjodeDims(1, 10, 1, 2, 50, 0, _lib.F_RESIDUAL)
     assert L.njode_supported(ctypes.byref(d)) == 1
     assert L.njode_param_count(ctypes.byref(d)) == 10071
-    d2 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, 0)
+    # a shape outside the build table runs on the shape-generic kernels ...
+    d3 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, 0)
+    assert L.njode_supported(ctypes.byref(d3)) == 1
+    assert L.njode_param_count(ctypes.byref(d3)) == (12 * 50 + 50) + (50 * 50 + 50) + (50 * 7 + 7) + \
+        (3 * 50 + 50) + (50 * 50 + 50) + (50 * 7 + 7) + (7 * 50 + 50) + (50 * 50 + 50) + (50 * 3 + 3)
+    # ... with per-network descriptions too
+    d4 = _lib.NjodeDims(2, 6, 2, 0, 0, 0, _lib.F_RESIDUAL)
+    d4.per_net = 1
+    d4.nets[0].n_hidden = 3
+    for l, w in enumerate((64, 32, 48)):
+        d4.nets[0].width[l] = w
+    d4.nets[1].n_hidden = 1
+    d4.nets[1].width[0] = 30
+    assert L.njode_supported(ctypes.byref(d4)) == 1
+    assert L.njode_param_count(ctypes.byref(d4)) == \
+        (10 * 64 + 64) + (64 * 32 + 32) + (32 * 48 + 48) + (48 * 6 + 6) + (2 * 30 + 30) + (30 * 6 + 6) + (6 * 2 + 2)
+    # ... except what no kernel family covers: a GRU jump outside the table, residual sizes
+    # that do not divide (the reference raises ValueError for those, models.py:243-249)
+    d2 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_USE_RNN)
     assert L.njode_supported(ctypes.byref(d2)) == 0
+    assert L.njode_supported(ctypes.byref(_lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_RESIDUAL))) == 0
     need = ctypes.c_size_t(0)
     assert L.njode_workspace_bytes(ctypes.byref(d), 100, 1000, 100, 100,
                                    _lib.C_GET_LOSS | _lib.C_SAVE_BWD, ctypes.byref(need)) == 0
     assert need.value > 100 * 100 * 10 * 4
     assert L.njode_workspace_bytes(ctypes.byref(d2), 100, 1000, 100, 100, 0,
                                    ctypes.byref(need)) == _lib.E_UNSUPPORTED
-    assert b'compiled' in L.njode_last_error()
+    assert b'use_rnn' in L.njode_last_error()
 
 
 def test_torch_library_operator_is_registered_with_a_fake_implementation():
