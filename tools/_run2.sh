@@ -1,6 +1,4 @@
-set -x
 mkdir -p gpurun_out/r3b
-timeout 2400 python -m pytest tests/test_hip_generic.py tests/test_hip_parity.py -x -q -m gpu -k "parity_suite or test_hip_parity" > gpurun_out/r3b/gen2.log 2>&1; echo "rc=$?" >> gpurun_out/r3b/gen2.log
-tail -30 gpurun_out/r3b/gen2.log
-NJODE_GENERIC=1 timeout 900 python tools/bench_generic.py > gpurun_out/r3b/bench_generic.jsonl 2> gpurun_out/r3b/bench_generic.err
-cat gpurun_out/r3b/bench_generic.jsonl; tail -3 gpurun_out/r3b/bench_generic.err
+NJODE_GENERIC=1 timeout 900 python tools/bench_generic.py > gpurun_out/r3b/bench_generic2.jsonl 2> gpurun_out/r3b/bench_generic2.err
+cat gpurun_out/r3b/bench_generic2.jsonl | cut -c1-330
+timeout 1200 python -m pytest tests/test_hip_generic.py tests/test_climate_eval.py tests/test_hip_convergence.py -x -q -m gpu -k "not parity_suite and not distribution" 2>&1 | tail -4
