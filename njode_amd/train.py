@@ -144,15 +144,34 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             for i, r in enumerate(saved_rows):
                 wr.writerow([i] + r)
 
-    metrics = []
-    pending = []
-    while model.epoch <= epochs:
-        t0 = time.time()
-        model.train()
-        order = train_idx[parallel.epoch_permutation(len(train_idx), model.epoch, shuffle_seed)]
+    def plan_epoch(epoch):
+        """Shuffled order of an epoch and (device collate) phase 1 of the collate for ALL of its
+        batches: the count kernels enqueued back to back, ONE copy to the host, ONE wait
+        (device_data.prepare_batches)."""
+        order = train_idx[parallel.epoch_permutation(len(train_idx), epoch, shuffle_seed)]
         n_steps = (len(order) + batch_size - 1) // batch_size
         if max_steps_per_epoch:
             n_steps = min(n_steps, max_steps_per_epoch)
+        prepared = None
+        if dev_ds is not None and n_steps > 0:
+            shards = []
+            for s_ in range(n_steps):
+                idx_ = order[s_ * batch_size:(s_ + 1) * batch_size]
+                lo_, hi_ = parallel.shard_range(len(idx_), world, rank)
+                shards.append(idx_[lo_:hi_])
+            live = [i for i, m_ in enumerate(shards) if len(m_)]
+            prepared = [None] * n_steps
+            for i, pr in zip(live, dev_ds.prepare_batches([shards[i] for i in live])):
+                prepared[i] = pr
+        return order, n_steps, prepared
+
+    metrics = []
+    pending = []
+    epoch_plan = {}
+    while model.epoch <= epochs:
+        t0 = time.time()
+        model.train()
+        order, n_steps, prepared = epoch_plan.pop(model.epoch, None) or plan_epoch(model.epoch)
         loss = None
         def prepare(s):
             idx = order[s * batch_size:(s + 1) * batch_size]
@@ -171,19 +190,6 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                 d = _device_batch(b, device)
             return idx, lo, mine, d
 
-        prepared = None
-        if dev_ds is not None and n_steps > 0:
-            # per-time observation counts of every batch of the epoch: all count kernels
-            # enqueued back to back, ONE copy to the host, ONE wait (device_data.prepare_batches)
-            shards = []
-            for s_ in range(n_steps):
-                idx_ = order[s_ * batch_size:(s_ + 1) * batch_size]
-                lo_, hi_ = parallel.shard_range(len(idx_), world, rank)
-                shards.append(idx_[lo_:hi_])
-            live = [i for i, m_ in enumerate(shards) if len(m_)]
-            prepared = [None] * n_steps
-            for i, pr in zip(live, dev_ds.prepare_batches([shards[i] for i in live])):
-                prepared[i] = pr
         # (NJODE_PLAN_AHEAD=0: A/B switch for the look-ahead)
         plan_ahead = plan_ahead and os.environ.get('NJODE_PLAN_AHEAD', '1') != '0'
         nxt = prepare(0) if n_steps > 0 else None
@@ -194,10 +200,14 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             # one batch ahead: the next batch is collated now, and (fused loop) its execution
             # plan is built on a helper stream beside this step (NJODE.prefetch_plan)
             nxt = prepare(s + 1) if s + 1 < n_steps else None
-            # (``plan_ahead_min``: smallest local batch that is planned ahead.  Round 2 used 4 096 --
-            # the loop was host-bound below that; with one host round trip per EPOCH in the device
-            # collate the host has slack at every batch size, profiles/r03_harness_epochs.jsonl)
-            if plan_ahead and fused and nxt is not None and len(nxt[2]) >= max(plan_ahead_min, 1):
+            # Where it pays (profiles/r03_harness_epochs.jsonl, epoch paths/s with / without):
+            # B = 100: 316 k / 297 k, B = 200: 572 k / 524 k -- the step is a chain of ~5 us
+            # launches and the plan's six are off it; B = 1 000: 1.83 M / 2.04 M -- the plan
+            # kernels queued ahead delay the step's own; B >= 4 096: the plan (~0.1 ms) hides
+            # beside the ODE kernels (bench.py: 1.19 -> 1.14 ms at 20 000 paths).
+            n_next = len(nxt[2]) if nxt is not None else 0
+            if plan_ahead and fused and n_next >= max(plan_ahead_min, 1) and \
+                    (n_next <= 512 or n_next >= 4096):
                 dn = nxt[3]
                 if dn.get('ready') is not None:
                     torch.cuda.current_stream().wait_event(dn['ready'])
@@ -220,6 +230,10 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                 for p in model.parameters():
                     parallel.allreduce_flat_(p.grad)
             optimizer.step()
+        # the next epoch's order and collate counts, queued behind this epoch's steps: its one
+        # host wait is the end-of-epoch wait the loop needs anyway
+        if dev_ds is not None and model.epoch + 1 <= epochs:
+            epoch_plan[model.epoch + 1] = plan_epoch(model.epoch + 1)
         torch.cuda.synchronize()
         train_time = time.time() - t0
 
