@@ -160,15 +160,29 @@ def cpu_baseline(meta_dt, T):
             'cpu_model': _cpu_model_name(), 'host_cpu_count': os.cpu_count()}
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r02_final_pmc_summary.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r03_final_pmc_summary.json')
+
+
+def _lib_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        with open(os.path.join(ROOT, 'njode_amd', 'libnjode_hip.so'), 'rb') as f:
+            for chunk in iter(lambda: f.read(1 << 20), b''):
+                h.update(chunk)
+    except OSError:
+        return None
+    return h.hexdigest()
 
 
 def measured_traffic(kernel, n_paths, dropout):
     """HBM bytes per launch of `kernel` as MEASURED on this build: profiles/
-    r02_final_pmc_summary.json is written by tools/summarize_pmc.py from `rocprofv3 --pmc
+    r03_final_pmc_summary.json is written by tools/summarize_pmc.py from `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `python bench.py` (recipe: profiles/README.md),
-    and records the workload it was taken on.  Returned only when that workload is the one
-    being benchmarked, else None (a counter cannot be collected inside this process).
+    and records the workload it was taken on AND the sha256 of the library it was taken with.
+    Returned only when that workload is the one being benchmarked on that very library, else
+    None (a counter cannot be collected inside this process; after any kernel change the
+    recipe has to be re-run).
     Units: rocprofv3 reports KiB.  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half
     the bytes of a coalesced streaming read, WRITE_SIZE is exact -- calibrated on this path's own
     pattern (one dword per lane, 256 B per wave access): the forward's WRITE_SIZE equals the
@@ -181,6 +195,8 @@ def measured_traffic(kernel, n_paths, dropout):
         return None, None
     wl = d.get('_workload', {})
     if wl.get('paths_per_gpu') != n_paths or abs(wl.get('dropout', -1) - dropout) > 1e-12:
+        return None, None
+    if wl.get('lib_sha256') != _lib_sha256():     # counters of another build: stale
         return None, None
     k = d.get(kernel, {})
     if k.get('FETCH_SIZE') is None or k.get('WRITE_SIZE') is None:

@@ -13,6 +13,7 @@ Usage:  python -m njode_amd.build [--force] [-j N]
 import argparse
 import concurrent.futures
 import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -73,6 +74,34 @@ def _digest(files, extra=''):
     return h.hexdigest()
 
 
+_RES_KEYS = {'VGPRs': 'vgpr', 'AGPRs': 'agpr', 'SGPRs': 'sgpr', 'ScratchSize [bytes/lane]': 'scratch',
+             'Occupancy [waves/SIMD]': 'occupancy', 'LDS Size [bytes/block]': 'lds_bytes',
+             'VGPRs Spill': 'vgpr_spill', 'SGPRs Spill': 'sgpr_spill'}
+
+
+def _parse_resources(out):
+    """(kernel -> resources, the rest of the compiler output) from -Rpass-analysis remarks."""
+    res, rest, cur = {}, [], None
+    for line in out.splitlines():
+        if 'remark:' in line and 'kernel-resource-usage' in line:
+            body = line.split('remark:', 1)[1].split('[-Rpass-analysis')[0].strip()
+            if body.startswith('Function Name:'):
+                cur = body.split(':', 1)[1].strip()
+                res[cur] = {}
+            elif cur is not None and ':' in body:
+                k, v = body.rsplit(':', 1)
+                k = _RES_KEYS.get(k.strip())
+                if k:
+                    try:
+                        res[cur][k] = int(v)
+                    except ValueError:
+                        pass
+        elif line.strip() and not line.lstrip().startswith(('|', '^', 'In file included from')) \
+                and '__global__' not in line and 'remarks generated' not in line:
+            rest.append(line)
+    return res, '\n'.join(rest)
+
+
 def _run(cmd):
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
@@ -93,7 +122,12 @@ def build(force=False, jobs=None, verbose=True):
         with open(inc_path, 'w') as f:
             f.write(inc)
     cc = _hipcc()
-    common = [cc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c']
+    # (-Rpass-analysis: the compiler's per-kernel register / scratch / LDS / occupancy remarks,
+    # parsed into _obj/kernel_resources.json -- what tools/summarize_pmc.py reports as a
+    # kernel's register count: rocprofv3's VGPR_Count column is the ARCH half of gfx950's
+    # unified register file only)
+    common = [cc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c',
+              '-Rpass-analysis=kernel-resource-usage']
     common += os.environ.get('NJODE_EXTRA_FLAGS', '').split()   # kernel experiments
     hdr = os.path.join(os.path.dirname(HERE), 'include', 'njode_hip.h')
     hdr_prod = os.path.join(os.path.dirname(HERE), 'include', 'njode_producer.h')
@@ -166,9 +200,12 @@ def build(force=False, jobs=None, verbose=True):
 
     def compile_one(t):
         out = _run(t[1])
+        res, rest = _parse_resources(out)
+        with open(t[0] + '.res.json', 'w') as f:
+            json.dump(res, f)
         with open(t[0] + '.stamp', 'w') as f:
             f.write(t[2])
-        return out
+        return rest
 
     # heaviest units first (masked 41-dim lockstep kernels dominate the wall time)
     todo.sort(key=lambda t: 0 if t[0].endswith(('_2.o', '_3.o')) else 1)
@@ -177,6 +214,14 @@ def build(force=False, jobs=None, verbose=True):
             if out.strip() and verbose:
                 print(out)
     _run([cc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + [t[0] for t in tasks])
+    merged = {}
+    for t in tasks:
+        if os.path.exists(t[0] + '.res.json'):
+            with open(t[0] + '.res.json') as f:
+                for k, v in json.load(f).items():
+                    merged.setdefault(k, v)
+    with open(os.path.join(OBJ, 'kernel_resources.json'), 'w') as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
     if verbose:
         print('[njode_amd.build] built', LIB)
     return LIB

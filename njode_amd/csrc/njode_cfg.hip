@@ -164,7 +164,7 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     hipStream_t s2 = side ? side->st : st;
     if (side) (void)hipStreamWaitEvent(s2, side->e0, 0);
     if constexpr (ODE == ODE_MFMA) {
-      ProfScope ps("k_pack_frags", s2);
+      ProfScope ps("k_pack_all", s2);
       launch_pack_frags<C>(a, s2);
     }
     {
@@ -176,12 +176,14 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       (void)hipEventRecord(side->e1, s2);
       (void)hipStreamWaitEvent(st, side->e1, 0);
     }
-    {
-      ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma" : "k_ode_fwd_items", st);
+    {   // (the names are the launched kernels', as rocprofv3 lists them)
+      ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_mixed" : "k_ode_fwd_mfma")
+                                   : "k_ode_fwd_items", st);
       launch_ode_fwd<DROP, false, ODE>(a, st);
     }
     if (tails) {
-      ProfScope ps(ODE == ODE_MFMA ? "k_ode_fwd_mfma.tails" : "k_ode_fwd_items.tails", st);
+      ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_split.tails" : "k_ode_fwd_mfma.tails")
+                                   : "k_ode_fwd_items.tails", st);
       launch_ode_fwd<DROP, true, ODE>(a, st);
     }
     if (!(ODE == ODE_MFMA && a.defer_loss)) {

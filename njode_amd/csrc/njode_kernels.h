@@ -48,7 +48,7 @@ struct KArgs {
   float* frag_enc;  // ... of the encoder and the readout (k_pack_net)
   float* frag_dec;
   float* frag2;     // scaled A-fragments of the ODE network (k_pack_frags2, njode_ode2.h)
-  const void* fragx;  // split-bf16 A-fragments of the ODE network (k_pack_frags_x, njode_odex.h)
+  const void* fragx;  // split-bf16 A-fragments of the ODE network (prototype kernels of tools/ubench/njode_odex.h only)
   // segment plan: the part of the plan the encoder rows do not need is built on a helper
   // stream beside them; the ODE kernel waits for this event (null: everything on one stream)
   void* plan_ready;

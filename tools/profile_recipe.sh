@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiling recipe of the headline bench (run on the GPU box from the repo root):
-#   bash tools/profile_recipe.sh <tag>          e.g. tag = r02_final
+#   bash tools/profile_recipe.sh <tag>          e.g. tag = r03_final
 # 1. rocprofv3 --kernel-trace --stats of `python3 bench.py` (the driver's command)
 # 2. PMC passes, ONE counter group per pass, kernels of the training step only, 3 steps:
 #    SQ group a / SQ group b / GRBM_GUI_ACTIVE (clock) / FETCH_SIZE / WRITE_SIZE
@@ -8,12 +8,12 @@
 # 3. tools/summarize_pmc.py -> gpurun_out/<tag>_pmc_summary.json (copy it to profiles/)
 # The program is named directly after `--` (no env / bash -c hop: see the pool's rules).
 set -u
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="$ROOT/bench.py --no-cpu-baseline --no-small-batch"
+BENCH="$ROOT/bench.py --no-cpu-baseline --no-small-batch --no-autograd-route"
 REGEX='k_ode|k_jump|k_encode|k_reduce|k_adam|k_pack|k_row_time|k_dense|k_traj|k_sum'
 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $BENCH --steps 20 \

@@ -9,8 +9,44 @@ narrow accesses are uncalibrated)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'njode_amd', 'libnjode_hip.so')
+RES = os.path.join(ROOT, 'njode_amd', 'csrc', '_obj', 'kernel_resources.json')
+
+
+def lib_sha256():
+    h = hashlib.sha256()
+    with open(LIB, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def compiler_resources():
+    """{demangled kernel name: resources} from the build's -Rpass-analysis remarks
+    (njode_amd/build.py).  rocprofv3's VGPR_Count column is only the ARCH half of gfx950's unified
+    register file (k_ode_bwd_mixed: 128 there, 256 in the code object); the compiler's number
+    is what decides the waves per SIMD."""
+    try:
+        with open(RES) as f:
+            res = json.load(f)
+    except OSError:
+        return {}
+    names = list(res)
+    try:
+        p = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt'], input='\n'.join(names),
+                           stdout=subprocess.PIPE, text=True, check=True)
+        dem = p.stdout.splitlines()
+    except (OSError, subprocess.CalledProcessError):
+        dem = names
+    return {d.replace('void ', '', 1): res[n] for n, d in zip(names, dem)}
+
 
 
 def short(name):
@@ -26,7 +62,10 @@ while argv and argv[0].startswith('--'):
     argv = argv[2:]
 out = collections.defaultdict(dict)
 if workload:
+    # the library the counters were taken on: bench.measured_traffic refuses any other build
+    workload['lib_sha256'] = lib_sha256()
     out['_workload'] = workload
+cres = compiler_resources()
 for d in argv:
     for path in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -34,10 +73,18 @@ for d in argv:
         for r in csv.DictReader(open(path)):
             k = short(r['Kernel_Name'])
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
-            meta[k] = {'vgpr': int(r['VGPR_Count']), 'agpr': int(r['Accum_VGPR_Count']),
+            meta[k] = {'arch_vgpr_rocprof': int(r['VGPR_Count']), 'agpr_rocprof': int(r['Accum_VGPR_Count']),
                        'sgpr': int(r['SGPR_Count']), 'lds_bytes': int(r['LDS_Block_Size']),
                        'scratch': int(r['Scratch_Size']), 'grid': int(r['Grid_Size']),
                        'workgroup': int(r['Workgroup_Size'])}
+            full = r['Kernel_Name'].replace('void ', '', 1)
+            cr = cres.get(full) or cres.get(full.split('(')[0])
+            if cr is None:      # (rocprofv3 may print the name without its parameter list)
+                hits = [v for n, v in cres.items() if n.split('(')[0] == full.split('(')[0]]
+                cr = hits[0] if hits else None
+            if cr:
+                meta[k].update({'vgpr': cr.get('vgpr'), 'agpr': cr.get('agpr'),
+                                'vgpr_spill': cr.get('vgpr_spill'), 'occupancy_waves_per_simd': cr.get('occupancy')})
         for k, counters in agg.items():
             if not k.startswith('k_'):
                 continue

@@ -30,7 +30,7 @@
 //     image [chain][unit] (one ds_write_b128 per k-step and piece) and read back transposed
 //     with ds_read_b64_tr_b16 -- no shuffles, no per-element LDS writes.
 #pragma once
-#include "njode_ode2.h"
+#include "../../njode_amd/csrc/njode_ode2.h"
 
 namespace njode {
 

@@ -18,7 +18,8 @@
 
 #include "../../njode_amd/csrc/njode_mfma_split.h"
 #include "../../njode_amd/csrc/njode_ode2.h"
-#include "../../njode_amd/csrc/njode_odex.h"
+#include "njode_ode2_proto.h"
+#include "njode_odex.h"
 
 using namespace njode;
 using C0 = Cfg<1, 10, 1, 2, 50, ACT_TANH, false, false, true, false>;
