@@ -201,6 +201,21 @@ NJ_DEV void layer_product(const float* __restrict__ ft, int Qp, int MT, lfp in, 
   }
 }
 
+// Diagnostic build (-DNJ_GEN_STAMPS): block 0 / thread 0 accumulates s_memtime deltas of the
+// phases of an Euler step into g_gen_stamps (read back by tools/ubench/gen_split.py through
+// njode_gen_debug_stamps); in the product build no stamp executes.
+#ifdef NJ_GEN_STAMPS
+__device__ unsigned long long g_gen_stamps[16];
+NJ_DEV void gstamp(int slot, unsigned long long& t) {
+  const unsigned long long now = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && slot >= 0) g_gen_stamps[slot] += now - t;
+  t = now;
+}
+#define GSTAMP(slot, t) gstamp(slot, t)
+#else
+#define GSTAMP(slot, t)
+#endif
+
 // ---- forward of one network on the tile -----------------------------------------------------
 // `in` holds the n_in input rows; returns the image that holds the n_out output rows.
 // rec != null: the layer inputs are stored to the evaluation record (training calls).
@@ -208,6 +223,9 @@ NJ_DEV void layer_product(const float* __restrict__ ft, int Qp, int MT, lfp in, 
 NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* rec, bool drop,
                        uint32_t dbase) {
   const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+#ifdef NJ_GEN_STAMPS
+  unsigned long long ts = __builtin_amdgcn_s_memtime();
+#endif
   for (int l = 0; l < N.nl; ++l) {
     const GLayer L = N.l[l];
     if (tid < 16) in[L.n_in * 16 + tid] = 1.0f;             // bias unit
@@ -216,6 +234,7 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
       for (int e = tid; e < L.n_in * 16; e += nth) dst[e] = in[e];
     }
     __syncthreads();
+    GSTAMP(4, ts);
     const bool hidden = l + 1 < N.nl;
     layer_product(a.frag + L.f_off, L.Qp, L.MT, in, [&](int mt, const f32x4& acc) {
 #pragma unroll
@@ -231,7 +250,9 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
         }
       }
     });
+    GSTAMP(5 + (l < 2 ? l : 2), ts);
     __syncthreads();
+    GSTAMP(8, ts);
     lfp t = in; in = other; other = t;
   }
   return in;
@@ -447,16 +468,41 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
   emit_row(G_TKEY_START - 1);
   write_row();
 
+  // the row of every chain at the NEXT jump time is fetched one jump ahead (jump times are visited
+  // in increasing order): its latency hides behind the evaluations in between
+  int row_pf = -1;
+  auto prefetch_rows = [&](int i) {
+    if (tid < 16)
+      row_pf = (i < a.n_times && b0 + tid < a.B && a.n_obs > 0) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
+  };
+  prefetch_rows(0);
+  constexpr int XR = 4;                       // observation values held in registers per thread
   for (int k = 0;; ++k) {
     // ---- jumps that happen before Euler step k
     for (int i = a.jlo[k]; i < a.jlo[k + 1]; ++i) {
-      if (tid < 16) S.rows[tid] = (b0 + tid < a.B && a.n_obs > 0) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
+      if (tid < 16) S.rows[tid] = row_pf;
+      prefetch_rows(i + 1);
       __syncthreads();
       bool any = false;
 #pragma unroll
       for (int c = 0; c < 16; ++c) any |= S.rows[c] >= 0;
       if (any) {
         const size_t jrec = (size_t)i * a.T + tile;
+        // observation and mask: loads issued now, consumed after the first readout
+        float xv[XR] = {0.f, 0.f, 0.f, 0.f}, mv[XR] = {0.f, 0.f, 0.f, 0.f};
+        const bool x_regs = a.D * 16 <= XR * nth;
+        if (x_regs) {
+#pragma unroll
+          for (int q = 0; q < XR; ++q) {
+            const int e = tid + q * nth;
+            const int ee = e < a.D * 16 ? e : 0;
+            const int r = S.rows[ee & 15];
+            const bool on = e < a.D * 16 && r >= 0;
+            const size_t src = (size_t)(on ? r : 0) * a.D + (ee >> 4);
+            xv[q] = on ? a.X[src] : 0.0f;
+            mv[q] = a.masked ? (on ? a.M[src] : 0.0f) : 1.0f;
+          }
+        }
         // y_bj = readout(h)
         dec_input(a, S.img0, S.h);
         __syncthreads();
@@ -469,12 +515,23 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
           dec_residual(a, S.ybj, S.h);
         }
         // observation, mask, encoder input (self-imputation in masked mode, models.py:463-467)
-        for (int e = tid; e < a.D * 16; e += nth) {
-          const int q = e >> 4, c = e & 15, r = S.rows[c];
-          const float xv = r >= 0 ? a.X[(size_t)r * a.D + q] : 0.0f;
-          const float mv = a.masked ? (r >= 0 ? a.M[(size_t)r * a.D + q] : 0.0f) : 1.0f;
-          S.xr[e] = xv;
-          S.mk[e] = mv;
+        if (x_regs) {
+#pragma unroll
+          for (int q = 0; q < XR; ++q) {
+            const int e = tid + q * nth;
+            if (e < a.D * 16) {
+              S.xr[e] = xv[q];
+              S.mk[e] = mv[q];
+            }
+          }
+        } else {
+          for (int e = tid; e < a.D * 16; e += nth) {
+            const int q = e >> 4, c = e & 15, r = S.rows[c];
+            const float xvv = r >= 0 ? a.X[(size_t)r * a.D + q] : 0.0f;
+            const float mvv = a.masked ? (r >= 0 ? a.M[(size_t)r * a.D + q] : 0.0f) : 1.0f;
+            S.xr[e] = xvv;
+            S.mk[e] = mvv;
+          }
         }
         __syncthreads();
         for (int e = tid; e < a.D * 16; e += nth)
@@ -544,14 +601,20 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
     if (k >= a.K) break;
     // ---- Euler step k (models.py:369-377)
     {
+#ifdef NJ_GEN_STAMPS
+      unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
       const float dt = a.step_dt[k], t = a.step_t[k];
       ode_input(a, S.img0, S.tx, S.h, tau, t);
       __syncthreads();
+      GSTAMP(0, t0);
       float* rec = a.save ? a.rec_ode + ((size_t)k * a.T + tile) * a.ode.rec_rows * 16 : nullptr;
       lfp out = net_forward(a, a.ode, S.img0, S.img1, rec, a.drop != 0,
                             drop_base(a.dc, gidc, (uint32_t)k, G_NET_ODE));
+      GSTAMP(1, t0);
       for (int e = tid; e < a.H * 16; e += nth) S.h[e] = fmaf(dt, out[e], S.h[e]);
       __syncthreads();
+      GSTAMP(2, t0);
       emit_row(0x80000000u + (uint32_t)k);
       write_row();
     }

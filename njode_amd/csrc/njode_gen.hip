@@ -458,3 +458,13 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
 
 }  // namespace gen
 }  // namespace njode
+
+#ifdef NJ_GEN_STAMPS
+// diagnostic build only: read and clear the phase stamps of njode_gen.h
+extern "C" int njode_gen_debug_stamps(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(njode::gen::g_gen_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long z[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(njode::gen::g_gen_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  return 0;
+}
+#endif

@@ -710,29 +710,6 @@ template <class C> struct OdeBwdMixedLds {
   static constexpr int A = OdeBwdActLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;
   static constexpr int FLOATS = A > B ? A : B;
 };
-template <class C> struct OdeBwdMixed2Lds {
-  static constexpr int A = OdeBwdPairLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;
-  static constexpr int FLOATS = A > B ? A : B;
-};
-// NJ_BWD_PAIR (build experiment, round 3): the bulk role carries two tiles per wave at one wave
-// per SIMD (ode3_bwd_pair, njode_ode2.h)
-#ifndef NJ_BWD_PAIR
-#define NJ_BWD_PAIR 0
-#endif
-#if NJ_BWD_PAIR
-template <class C, bool DROP>
-__global__ void __launch_bounds__(256, 1) k_ode_bwd_mixed(KArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdMixed2Lds<C>::FLOATS];
-  const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_blocks;
-  const int T = (int)a.base_s[a.K + 1];
-  if ((int)blockIdx.x < ns) {
-    ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
-  } else {
-    const int wave = ((int)blockIdx.x - ns) * 4 + (threadIdx.x >> 6);
-    ode3_bwd_pair<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
-  }
-}
-#else
 // one slab row per block
 template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
@@ -748,6 +725,5 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
     ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
   }
 }
-#endif
 
 }  // namespace njode

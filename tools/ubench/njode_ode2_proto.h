@@ -3,6 +3,8 @@
 // product translation unit includes this file.
 //   * ode2_bwd_single: the one-wave backward that RECOMPUTES the hidden layers, on the scaled
 //     fragments (superseded by ode3_bwd_single on stored activations, njode_ode2.h);
+//   * ode3_bwd_pair (round 3): two tiles per wave at one wave per SIMD, 0.60-0.66 ms against
+//     0.50 ms for two waves per SIMD with one tile each (profiles/r03_bwd_experiments.jsonl);
 //   * k_ode2_bwd_pc: producer / consumer split of the sweep inside a 512-thread block (correct,
 //     no gain: f32 MFMA and VALU share one pipe, both halves sit on it).
 #pragma once
@@ -627,6 +629,300 @@ __global__ void __launch_bounds__(512, 2) k_ode2_bwd_pc(KArgs a) {
   } else {
     ode2_bwd_consumer<C>(a, lds, wv - 4, lane, n_tiles, blockIdx.x, DROP ? a.dc.inv_keep : 1.0f);
   }
+}
+
+
+
+// ---- C (stored activations), TWO tiles per wave (round 3) ------------------------------------
+// ode3_bwd_single at two waves per SIMD leaves the shared f32 pipe ~1/3 idle: a lone wave keeps
+// it ~60 % busy, and the partner's instructions come out of the same pipe.  Here
+// ONE wave per SIMD (512 registers) carries two independent tiles through the sweep: the
+// compiler interleaves the two dependency chains statically (a tile's LDS round trips and
+// MFMA -> VALU hazards are covered by the other tile's MFMAs), every A-fragment read from LDS
+// feeds two MFMAs, and both tiles accumulate into ONE set of dW tiles (K = 32 chains per step).
+// Tiles 2p and 2p + 1 of the length-sorted order are paired: (almost) equal lengths.
+template <class C> struct OdeBwdPairLds {
+  using M = MF<C>;
+  static constexpr int NG = OdeBwdActLds<C>::NG;
+  static constexpr int BODY = 4 * 4 * IMG_FLOATS + OdeLdsFragsT<C>::NVEC * 64;
+  static constexpr int RED = 3 * NG * 64 * 4;
+  static constexpr int FLOATS = BODY > RED ? BODY : RED;
+};
+template <class C, bool DROP>
+NJ_DEV void ode3_bwd_pair(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
+                          int slab_row) {
+  using M = MF<C>;
+  using NL = typename C::Ode;
+  using FR = OdeLdsFragsT<C>;
+  constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
+  constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  lfp img_d[2], img_a[2];
+  img_d[0] = lds_raw + wv * 4 * IMG_FLOATS;
+  img_a[0] = img_d[0] + IMG_FLOATS;
+  img_d[1] = img_a[0] + IMG_FLOATS;
+  img_a[1] = img_d[1] + IMG_FLOATS;
+  lfp fimg = lds_raw + 4 * 4 * IMG_FLOATS;
+  FR::stage(fimg, a.frag2, threadIdx.x, 256);
+  for (int i = threadIdx.x; i < 4 * 4 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  __syncthreads();
+  FR F;
+  F.init(fimg, lane);
+
+  f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < M::MTH; ++i)
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G3[i][n] = zero4;
+#pragma unroll
+  for (int i = 0; i < M::MT1; ++i) {
+#pragma unroll
+    for (int n = 0; n < NT1; ++n) G2[i][n] = zero4;
+#pragma unroll
+    for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
+  }
+  float* const trash = a.trash + threadIdx.x * C::H;
+  const int n_tiles = tile1 - tile0;
+  const int n_pairs = (n_tiles + 1) / 2;
+  for (int round = 0; round * n_waves < n_pairs; ++round) {
+    const int rel = snake_tile(round, wave, n_waves);
+    if (rel >= n_pairs) continue;
+    int tile[2], j[2];
+    bool valid[2];
+    Item<C> it[2];
+    float lam[2][M::QH];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tl = tile0 + 2 * rel + t;
+      tile[t] = tl < tile1 ? tl : tile1 - 1;          // odd tail: tile repeated with no valid item
+      j[t] = tile[t] * 16 + c;
+      valid[t] = tl < tile1 && j[t] < a.n_obs;
+      it[t].template load<false>(a, j[t], valid[t]);
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        const float v = a.lam_end[(size_t)it[t].r * C::H + (u < C::H ? u : 0)];
+        lam[t][q] = (valid[t] && u < C::H) ? v : 0.0f;
+      }
+    }
+    const int nmax = wave_max(it[0].n > it[1].n ? it[0].n : it[1].n);
+    auto fetch = [&](int t, int s, float (&hh)[M::QH], float (&x1)[M::Q1], float (&x2)[M::Q1], float& dtt,
+                     float& tt) {
+      const bool act = s < it[t].n;
+      const int kk = act ? it[t].kbeg + s : 0;
+      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j[t]) * C::H : 0);
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        const float v = rec[u < C::H ? u : 0];
+        hh[q] = u < C::H ? v : 0.0f;
+      }
+      act_load<C>(a.act, a.base16_s[s], tile[t], lane, x1, x2);
+      dtt = act ? a.step_dt[kk] : 0.0f;
+      tt = a.step_t[kk];
+    };
+    float h_n[2][M::QH], a1_n[2][M::Q1], a2_n[2][M::Q1], dt_n[2] = {0.0f, 0.0f}, t_n[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) h_n[t][q] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q) { a1_n[t][q] = 0.0f; a2_n[t][q] = 0.0f; }
+    }
+    if (nmax > 0) {
+      fetch(0, nmax - 1, h_n[0], a1_n[0], a2_n[0], dt_n[0], t_n[0]);
+      fetch(1, nmax - 1, h_n[1], a1_n[1], a2_n[1], dt_n[1], t_n[1]);
+    }
+    for (int s = nmax - 1; s >= 0; --s) {
+      float h[2][M::QH], a1[2][M::Q1], a2[2][M::Q1], dt[2], tm[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int q = 0; q < M::QH; ++q) h[t][q] = h_n[t][q];
+#pragma unroll
+        for (int q = 0; q < M::Q1; ++q) { a1[t][q] = a1_n[t][q]; a2[t][q] = a2_n[t][q]; }
+        dt[t] = dt_n[t];
+        tm[t] = t_n[t];
+      }
+      if (s > 0) {
+        fetch(0, s - 1, h_n[0], a1_n[0], a2_n[0], dt_n[0], t_n[0]);
+        fetch(1, s - 1, h_n[1], a1_n[1], a2_n[1], dt_n[1], t_n[1]);
+      }
+      float b0[2][M::Q0];
+      in0_fill<C, 0>(b0[0], h[0], it[0].tx, it[0].tau, tm[0] - it[0].tau, g);
+      in0_fill<C, 0>(b0[1], h[1], it[1].tx, it[1].tau, tm[1] - it[1].tau, g);
+      F.begin();
+
+      // ---- layer 3: delta3 = dt * lam (zero for inactive chains)
+      float d3[2][M::QH];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int q = 0; q < M::QH; ++q) d3[t][q] = dt[t] * lam[t][q];
+        img_write<M::QH>(img_d[t], d3[t], g, c);
+        img_write<M::Q1>(img_a[t], a2[t], g, c);
+      }
+      wave_lds_sync();
+      dw_accumulate<M::MTH, NT1>(img_d[0], img_a[0], G3, g, c);
+      dw_accumulate<M::MTH, NT1>(img_d[1], img_a[1], G3, g, c);
+      f32x4 acc[2][M::MT1];
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) { acc[0][mt] = zero4; acc[1][mt] = zero4; }
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) {
+          const float fr = F.b3(mt, q);               // one fragment read, two MFMAs
+          acc[0][mt] = mfma4(fr, d3[0][q], acc[0][mt]);
+          acc[1][mt] = mfma4(fr, d3[1][q], acc[1][mt]);
+        }
+      float d2[2][M::QW];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < M::QW; ++q)
+          d2[t][q] = acc[t][q / 4][q % 4] * dact_stored<C::ACT, DROP>(a2[t][q]);
+      wave_lds_sync();
+
+      // ---- layer 2
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        img_write<M::QW>(img_d[t], d2[t], g, c);
+        img_write<M::Q1>(img_a[t], a1[t], g, c);
+      }
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT1>(img_d[0], img_a[0], G2, g, c);
+      dw_accumulate<M::MT1, NT1>(img_d[1], img_a[1], G2, g, c);
+#pragma unroll
+      for (int mt = 0; mt < M::MT1; ++mt) { acc[0][mt] = zero4; acc[1][mt] = zero4; }
+#pragma unroll
+      for (int q = 0; q < M::QW; ++q)
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) {
+          const float fr = F.b2(mt, q);
+          acc[0][mt] = mfma4(fr, d2[0][q], acc[0][mt]);
+          acc[1][mt] = mfma4(fr, d2[1][q], acc[1][mt]);
+        }
+      float d1[2][M::QW];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < M::QW; ++q)
+          d1[t][q] = acc[t][q / 4][q % 4] * dact_stored<C::ACT, DROP>(a1[t][q]);
+      wave_lds_sync();
+
+      // ---- layer 1
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        img_write<M::QW>(img_d[t], d1[t], g, c);
+        img_write<M::Q0>(img_a[t], b0[t], g, c);
+      }
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT0>(img_d[0], img_a[0], G1, g, c);
+      dw_accumulate<M::MT1, NT0>(img_d[1], img_a[1], G1, g, c);
+      f32x4 acch[2][M::MTH];
+#pragma unroll
+      for (int mt = 0; mt < M::MTH; ++mt) {
+        f32x4 e0 = zero4, e1 = zero4;
+#pragma unroll
+        for (int q = 0; q < M::QW; ++q) {
+          const float fr = F.b1(mt, q);
+          e0 = mfma4(fr, d1[0][q], e0);
+          e1 = mfma4(fr, d1[1][q], e1);
+        }
+        acch[0][mt] = e0;
+        acch[1][mt] = e1;
+      }
+      // adjoint of the state: lam += (W1^T delta1)[h rows] * (1 - tanh(h)^2)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < M::QH; ++q) {
+          const float th = b0[t][q];  // = tanh(h) wherever unit 4q + g < H
+          const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
+          lam[t][q] = fmaf(acch[t][q / 4][q % 4], dth, lam[t][q]);
+        }
+      wave_lds_sync();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float* out = valid[t] ? a.lam_start + (size_t)it[t].r * C::H : trash;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        float* dst = u < C::H ? out + u : trash;
+        *dst = lam[t][q];
+      }
+    }
+  }
+
+  // ---- flush (as ode3_bwd_single): one slab row per block
+  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
+  static_assert(3 * NG * 64 * 4 <= OdeBwdPairLds<C>::FLOATS, "tile reduction does not fit the LDS");
+  __syncthreads();
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
+  auto for_tiles = [&](auto f) {
+    int i = 0;
+#pragma unroll
+    for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT0; ++nt) f(G1[mt][nt], i++);
+  };
+  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+  __syncthreads();
+  if (wv != 0) return;
+  for_tiles([&](f32x4& t, int i) {
+    t += red[(0 * NG + i) * 64 + lane];
+    t += red[(1 * NG + i) * 64 + lane];
+    t += red[(2 * NG + i) * 64 + lane];
+  });
+  const float ik = DROP ? a.dc.inv_keep : 1.0f;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < M::W) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W2[uo * M::W + ui] = ik * G2[mt][nt][r];
+          else if (ui == M::W) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::IN0) W1[uo * M::IN0 + M::col0(ui)] = G1[mt][nt][r];
+          else if (ui == M::IN0) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < C::H) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W3[uo * M::W + ui] = ik * G3[mt][nt][r];
+          else if (ui == M::W) b3[uo] = G3[mt][nt][r];
+        }
+      }
+    }
 }
 
 
