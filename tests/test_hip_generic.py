@@ -166,11 +166,11 @@ def test_generic_dropout_gradient_matches_finite_differences():
 
 def test_generic_dropout_loss_distribution_matches_oracle():
     cfg = _cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1)
-    b, meta = bs_batch(96, seed=4)
+    b, meta = bs_batch(64, seed=4)
     torch.manual_seed(0)
     m = hip_model(cfg).train()
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    n = 150
+    n = 60          # (each oracle draw at width 100 is ~2 s of CPU)
     with torch.no_grad():
         hip = np.array([float(hip_forward(m, b, meta['dt'], meta['maturity'])[1]) for _ in range(n)])
     torch.manual_seed(123)
@@ -216,3 +216,20 @@ def test_generic_shards_add_up_and_edge_cases():
         (h_o, _), _ = oracle_forward(cfg, sd, empty, dt, T, get_loss=False, until_T=True)
     assert float(loss0) == 0.0
     np.testing.assert_allclose(hT.cpu().numpy(), h_o.numpy(), atol=ATOL, rtol=RTOL)
+
+
+def test_harness_trains_a_width_100_model():
+    """njode_amd.train.train (fused loop, device collate, dropout 0.1) on the shape of
+    parallel_train.py:609 -- three hidden-100 networks -- for a few epochs: the validation loss
+    falls towards the optimal loss, as it does for the demo shape on the specialised kernels."""
+    from njode_amd import data_utils, train
+    hp = dict(data_utils.hyperparam_default, nb_paths=2000)
+    paths, obs, nb_obs, meta = data_utils.create_dataset('BlackScholes', hp, seed=0)
+    nn = _w(100)
+    _, metrics = train.train((paths, obs, nb_obs), meta, epochs=6, batch_size=100, ode_nn=nn,
+                             readout_nn=nn, enc_nn=nn, dropout_rate=0.1, log=lambda s: None,
+                             device_collate=True)
+    ev = [m[4] for m in metrics]
+    opt = metrics[0][5]
+    assert all(np.isfinite(ev))
+    assert ev[-1] < 0.8 * ev[0] and ev[-1] > 0.9 * opt
