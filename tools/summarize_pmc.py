@@ -39,12 +39,15 @@ def compiler_resources():
     except OSError:
         return {}
     names = list(res)
-    try:
-        p = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt'], input='\n'.join(names),
-                           stdout=subprocess.PIPE, text=True, check=True)
-        dem = p.stdout.splitlines()
-    except (OSError, subprocess.CalledProcessError):
-        dem = names
+    dem = names
+    for tool in ('c++filt', '/opt/rocm/lib/llvm/bin/llvm-cxxfilt'):
+        try:
+            p = subprocess.run([tool], input='\n'.join(names), stdout=subprocess.PIPE, text=True,
+                               check=True)
+            dem = p.stdout.splitlines()
+            break
+        except (OSError, subprocess.CalledProcessError):
+            continue
     return {d.replace('void ', '', 1): res[n] for n, d in zip(names, dem)}
 
 
