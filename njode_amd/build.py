@@ -138,7 +138,7 @@ def build(force=False, jobs=None, verbose=True):
                     'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
                     'njode_mfma_lock4.h')] + [hdr]
     gen_deps = [os.path.join(CSRC, n) for n in
-                ('njode_gen.hip', 'njode_gen.h', 'njode_gen_host.h', 'njode_device.h',
+                ('njode_gen.hip', 'njode_gen.h', 'njode_gen_seg.h', 'njode_gen_host.h', 'njode_device.h',
                  'njode_error.h')] + [hdr]
     api_deps = [os.path.join(CSRC, n) for n in
                 ('njode_api.hip', 'njode_gen_host.h', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',

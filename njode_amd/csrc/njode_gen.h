@@ -789,6 +789,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
 struct GDw {
   const float* rec;      // records of this network
   long long n_rec;       // number of records
+  const int* n_rec_dev;  // non-null: the number of records lives on the device (segment plan)
   int rec_floats;        // floats per record
   const int* flags;      // per flag group 0 / 1, or null (all active)
   int flag_div;          // record r belongs to flag group r / flag_div
@@ -827,7 +828,8 @@ __global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
     bone[j] = u == d.n_in;            // bias column: input = 1
     brow[j] = d.a_row + (bok[j] ? u : 0);
   }
-  for (long long r = (long long)blockIdx.y * 4 + wv; r < d.n_rec; r += stride) {
+  const long long n_rec = d.n_rec_dev ? (long long)d.n_rec_dev[0] : d.n_rec;
+  for (long long r = (long long)blockIdx.y * 4 + wv; r < n_rec; r += stride) {
     if (d.flags && r < d.n_flagged && !d.flags[r / d.flag_div]) continue;   // wave-uniform
     const float* rec = d.rec + (size_t)r * d.rec_floats;
     f4 af[DW_TM], bf[DW_TN];

@@ -9,9 +9,12 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rocprim/rocprim.hpp>
+
 #include "../../include/njode_hip.h"
 #include "njode_error.h"
 #include "njode_gen.h"
+#include "njode_gen_seg.h"
 #include "njode_gen_host.h"
 
 namespace njode {
@@ -171,7 +174,15 @@ struct Layout {
   size_t total = 0;
   size_t sched, jlo, dense, bad, plan_end;
   size_t frag, loss_terms, slab, rec_ode, rec_enc, rec_dec, ybuf, flags;
+  // segment plan (unmasked loss calls): plan prefix ...
+  size_t t_of_row, item_prev, item_next, item_kbeg, item_len, key, key_sorted, iota, order,
+      first_row, last_row, tail_key, tail_key_sorted, iota_b, tail_order, tile_base, sort_tmp;
+  size_t sort_tmp_bytes = 0;
+  // ... and per-call arrays
+  size_t h0row, h0start, h_end, lam_end, g_h0, lam_start;
   int T;
+  int NT = 0;       // item tiles = row tiles
+  bool seg = false;
   size_t take(size_t bytes) {
     size_t off = total;
     total += (bytes + 255) & ~(size_t)255;
@@ -179,20 +190,79 @@ struct Layout {
   }
 };
 
+inline int bits_for(unsigned v) {  // radix bits needed for keys in [0, v]
+  int b = 1;
+  while (b < 32 && (v >> b)) ++b;
+  return b;
+}
+hipError_t sort_pairs(void* tmp, size_t& bytes, const unsigned* k_in, unsigned* k_out, const int* v_in,
+                      int* v_out, int n, int end_bit, hipStream_t st) {
+  return rocprim::radix_sort_pairs(tmp, bytes, k_in, k_out, v_in, v_out, (size_t)(n > 0 ? n : 1), 0u,
+                                   (unsigned)end_bit, st);
+}
+
+// The segment plan (njode_gen_seg.h) serves the unmasked calls that ask for the loss and not for
+// the path: training and loss-only evaluation.  NJODE_GEN_PLAN=lock keeps them on the lockstep
+// plan (A/B measurements; tests compare the two plans).
+bool use_seg(const Model& m, int n_obs, int call_flags) {
+  const char* env = getenv("NJODE_GEN_PLAN");     // (read per call: tests switch it)
+  const bool lock_only = env && strcmp(env, "lock") == 0;
+  return !lock_only && !m.a.masked && n_obs > 0 && (call_flags & NJODE_C_GET_LOSS) &&
+         !(call_flags & NJODE_C_RETURN_PATH);
+}
+
 Layout make_layout(const Model& m, int B, int n_obs, int nt, int K, int call_flags) {
   Layout L;
   L.T = cdiv(B, 16);
+  L.seg = use_seg(m, n_obs, call_flags);
+  L.NT = L.seg ? cdiv(n_obs, 16) : 0;
   const size_t T = (size_t)L.T, ntl = (size_t)(nt > 0 ? nt : 1);
+  const size_t nr = (size_t)(n_obs > 0 ? n_obs : 1), nb = (size_t)B;
   L.sched = L.take(((size_t)2 * K + 3 * (size_t)nt + 1) * 4 + 64);
   L.jlo = L.take(((size_t)K + 2) * 4);
   L.dense = L.take(ntl * (size_t)B * 4);
   L.bad = L.take(256);
+  if (L.seg) {
+    L.t_of_row = L.take(nr * 4);
+    L.item_prev = L.take(nr * 4);
+    L.item_next = L.take(nr * 4);
+    L.item_kbeg = L.take(nr * 4);
+    L.item_len = L.take(nr * 4);
+    L.key = L.take(nr * 4);
+    L.key_sorted = L.take(nr * 4);
+    L.iota = L.take(nr * 4);
+    L.order = L.take(nr * 4);
+    L.first_row = L.take(nb * 4);
+    L.last_row = L.take(nb * 4);
+    L.tail_key = L.take(nb * 4);
+    L.tail_key_sorted = L.take(nb * 4);
+    L.iota_b = L.take(nb * 4);
+    L.tail_order = L.take(nb * 4);
+    L.tile_base = L.take(((size_t)L.NT + 1) * 4);
+    size_t b0 = 0, b1 = 0;
+    (void)sort_pairs(nullptr, b0, nullptr, nullptr, nullptr, nullptr, n_obs, bits_for((unsigned)K), (hipStream_t)0);
+    (void)sort_pairs(nullptr, b1, nullptr, nullptr, nullptr, nullptr, B, bits_for((unsigned)K), (hipStream_t)0);
+    L.sort_tmp_bytes = b0 > b1 ? b0 : b1;
+    L.sort_tmp = L.take(L.sort_tmp_bytes);
+  }
   L.plan_end = L.total;
   L.frag = L.take((size_t)m.frag_floats * 4);
-  L.loss_terms = L.take((size_t)B * 4);
+  L.loss_terms = L.take((nr > nb ? nr : nb) * 4);
+  if (L.seg) {
+    const size_t H = (size_t)m.a.H;
+    L.h0row = L.take(nr * H * 4);
+    L.h0start = L.take(nb * H * 4);
+    L.h_end = L.take(nr * H * 4);
+    if (call_flags & NJODE_C_SAVE_BWD) {
+      L.lam_end = L.take(nr * H * 4);
+      L.g_h0 = L.take(nr * H * 4);
+      L.lam_start = L.take(nr * H * 4);
+    }
+  }
   if (call_flags & NJODE_C_SAVE_BWD) {
     L.slab = L.take((size_t)m.S * m.P * 4);
-    L.rec_ode = L.take((size_t)(K > 0 ? K : 1) * T * m.a.ode.rec_rows * 64);
+    // (segment plan: sum over the item tiles of their longest item <= K + B K / 16 records)
+    L.rec_ode = L.take(((size_t)(K > 0 ? K : 1) * (T + 1) + 1) * m.a.ode.rec_rows * 64);
     L.rec_enc = L.take(((size_t)nt * T + T) * m.a.enc.rec_rows * 64);
     L.rec_dec = L.take(ntl * T * 2 * m.a.dec.rec_rows * 64);
     L.ybuf = L.take(ntl * T * 2 * m.a.DO * 64);
@@ -248,6 +318,23 @@ int build_plan(const Layout& L, char* pw, const NjodeBatch* b, const NjodeSchedu
   if (nt > 0) HIP_TRY(hipMemsetAsync(dense, 0xFF, (size_t)nt * B * 4, st));
   if (n > 0) k_gen_rows<<<cdiv(n, 256), 256, 0, st>>>(time_ptr, nt, n, b->obs_idx, B, dense, bad);
   k_gen_jlo<<<cdiv(K + 2, 256), 256, 0, st>>>(k_jump, nt, K, (int*)(pw + L.jlo));
+  if (L.seg) {
+    // items = rows linked along their path, sorted by length; tails sorted by length
+    k_gseg_link<<<cdiv(B, 64), 64, 0, st>>>(
+        B, nt, K, dense, k_jump, (int*)(pw + L.t_of_row), (int*)(pw + L.item_prev), (int*)(pw + L.item_next),
+        (int*)(pw + L.item_kbeg), (int*)(pw + L.item_len), (unsigned*)(pw + L.key), (int*)(pw + L.first_row),
+        (int*)(pw + L.last_row), (unsigned*)(pw + L.tail_key), (int*)(pw + L.iota_b));
+    k_gseg_iota<<<cdiv(n, 256), 256, 0, st>>>(n, (int*)(pw + L.iota));
+    size_t bytes = L.sort_tmp_bytes;
+    HIP_TRY(sort_pairs(pw + L.sort_tmp, bytes, (const unsigned*)(pw + L.key), (unsigned*)(pw + L.key_sorted),
+                       (const int*)(pw + L.iota), (int*)(pw + L.order), n, bits_for((unsigned)K), st));
+    bytes = L.sort_tmp_bytes;
+    HIP_TRY(sort_pairs(pw + L.sort_tmp, bytes, (const unsigned*)(pw + L.tail_key),
+                       (unsigned*)(pw + L.tail_key_sorted), (const int*)(pw + L.iota_b),
+                       (int*)(pw + L.tail_order), B, bits_for((unsigned)K), st));
+    k_gseg_tiles<<<1, 1024, 0, st>>>((const int*)(pw + L.order), (const int*)(pw + L.item_len), n, L.NT,
+                                     (int*)(pw + L.tile_base));
+  }
   static const bool validate = getenv("NJODE_VALIDATE") && atoi(getenv("NJODE_VALIDATE")) != 0;
   if (validate) {
     int h = 0;
@@ -263,6 +350,7 @@ struct Call {
   Model m;
   Layout L;
   GArgs a;
+  GSeg g;
 };
 
 int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatch* b,
@@ -320,6 +408,33 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
   a.keep = 1.0f - (float)a.dc.thr16 / 65536.0f;
   a.dc.inv_keep = 1.0f / a.keep;
   a.weight = weight;
+  memset(&c.g, 0, sizeof(c.g));
+  if (c.L.seg) {
+    GSeg& g = c.g;
+    g.order = (const int*)(pw + c.L.order);
+    g.item_prev = (const int*)(pw + c.L.item_prev);
+    g.item_next = (const int*)(pw + c.L.item_next);
+    g.item_kbeg = (const int*)(pw + c.L.item_kbeg);
+    g.item_len = (const int*)(pw + c.L.item_len);
+    g.t_of_row = (const int*)(pw + c.L.t_of_row);
+    g.first_row = (const int*)(pw + c.L.first_row);
+    g.last_row = (const int*)(pw + c.L.last_row);
+    g.tile_base = (const int*)(pw + c.L.tile_base);
+    g.tail_order = (const int*)(pw + c.L.tail_order);
+    g.k_jump = (const int*)(sb + 2 * (size_t)K);
+    g.obs_idx = b->obs_idx;
+    g.NT = c.L.NT;
+    g.TB = c.L.T;
+    g.h0row = (float*)(w + c.L.h0row);
+    g.h0start = (float*)(w + c.L.h0start);
+    g.h_end = (float*)(w + c.L.h_end);
+    if (a.save) {
+      g.lam_end = (float*)(w + c.L.lam_end);
+      g.g_h0 = (float*)(w + c.L.g_h0);
+      g.lam_start = (float*)(w + c.L.lam_start);
+    }
+    g.loss_rows = a.loss_terms;
+  }
   return NJODE_OK;
 }
 
@@ -390,6 +505,28 @@ int gen_forward(const NjodeDims* dims, const float* params, const NjodeBatch* b,
     Prof ps("k_gen_pack", st);
     k_gen_pack<<<cdiv(c.m.pack.total, 256), 256, 0, st>>>(params, (float*)c.a.frag, c.m.pack);
   }
+  if (c.L.seg) {
+    const int nth = c.m.nw * 64, lds = c.m.lds_bytes;
+    c.g.tails = hT != nullptr;
+    if ((rc = set_lds((const void*)k_gseg_enc, lds)) || (rc = set_lds((const void*)k_gseg_ode_fwd, lds)) ||
+        (rc = set_lds((const void*)k_gseg_mid, lds)))
+      return rc;
+    {
+      Prof ps("k_gseg_enc", st);
+      k_gseg_enc<<<c.g.NT + c.g.TB, nth, lds, st>>>(c.a, c.g);
+    }
+    {
+      Prof ps("k_gseg_ode_fwd", st);
+      k_gseg_ode_fwd<<<c.g.NT + (c.g.tails ? c.g.TB : 0), nth, lds, st>>>(c.a, c.g);
+    }
+    {
+      Prof ps("k_gseg_mid", st);
+      k_gseg_mid<<<c.g.NT, nth, lds, st>>>(c.a, c.g);
+    }
+    k_gen_sum<<<1, 1024, 0, st>>>(c.a.loss_terms, b->n_obs, loss);
+    HIP_TRY(hipGetLastError());
+    return NJODE_OK;
+  }
   if (c.a.save) HIP_TRY(hipMemsetAsync(c.a.flags, 0, (size_t)(s->n_times > 0 ? s->n_times : 1) * c.L.T * 4, st));
   if ((rc = set_lds((const void*)k_gen_fwd, c.m.lds_bytes))) return rc;
   {
@@ -412,14 +549,27 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
   if (!(call_flags & NJODE_C_SAVE_BWD) || !(call_flags & NJODE_C_GET_LOSS))
     return fail(NJODE_E_BADARG, "backward needs a forward with NJODE_C_SAVE_BWD | NJODE_C_GET_LOSS");
   // (schedule copy, plan, fragment tables and records are where the forward left them)
-  if ((rc = set_lds((const void*)k_gen_bwd, c.m.lds_bytes))) return rc;
-  {
+  if (c.L.seg) {
+    const int nth = c.m.nw * 64, lds = c.m.lds_bytes;
+    if ((rc = set_lds((const void*)k_gseg_ode_bwd, lds)) || (rc = set_lds((const void*)k_gseg_enc_bwd, lds)))
+      return rc;
+    {
+      Prof ps("k_gseg_ode_bwd", st);
+      k_gseg_ode_bwd<<<c.g.NT, nth, lds, st>>>(c.a, c.g);
+    }
+    {
+      Prof ps("k_gseg_enc_bwd", st);
+      k_gseg_enc_bwd<<<c.g.NT + c.g.TB, nth, lds, st>>>(c.a, c.g);
+    }
+  } else {
+    if ((rc = set_lds((const void*)k_gen_bwd, c.m.lds_bytes))) return rc;
     Prof ps("k_gen_bwd", st);
     k_gen_bwd<<<c.L.T, c.m.nw * 64, c.m.lds_bytes, st>>>(c.a);
   }
   float* slab = (float*)((char*)ws + c.L.slab);
   const GArgs& a = c.a;
   const long long T = c.L.T, nt = a.n_times;
+  const int* n_rec_dev = nullptr;
   auto dw = [&](const GNet& N, const float* rec, long long n_rec, const int* flags, int flag_div,
                 long long n_flagged) {
     for (int l = 0; l < N.nl; ++l) {
@@ -427,6 +577,7 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
       GDw d;
       d.rec = rec;
       d.n_rec = n_rec;
+      d.n_rec_dev = n_rec_dev;
       d.rec_floats = N.rec_rows * 16;
       d.flags = flags;
       d.flag_div = flag_div;
@@ -445,7 +596,14 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
       k_gen_dw<<<dim3(tb, c.m.S), 256, 0, st>>>(d);
     }
   };
-  {
+  if (c.L.seg) {
+    Prof ps("k_gen_dw", st);
+    n_rec_dev = c.g.tile_base + c.g.NT;        // the number of ODE records is known on the device only
+    dw(a.ode, a.rec_ode, (long long)a.K * (T + 1) + 1, nullptr, 1, 0);
+    n_rec_dev = nullptr;
+    dw(a.enc, a.rec_enc, (long long)c.g.NT + c.g.TB, nullptr, 1, 0);
+    dw(a.dec, a.rec_dec, (long long)c.g.NT * 2, nullptr, 1, 0);
+  } else {
     Prof ps("k_gen_dw", st);
     dw(a.ode, a.rec_ode, (long long)a.K * T, nullptr, 1, 0);
     dw(a.enc, a.rec_enc, nt * T + T, a.flags, 1, nt * T);

@@ -233,3 +233,50 @@ def test_harness_trains_a_width_100_model():
     opt = metrics[0][5]
     assert all(np.isfinite(ev))
     assert ev[-1] < 0.8 * ev[0] and ev[-1] > 0.9 * opt
+
+
+PLAN_CASES = {
+    'w100_dropout': (_cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1), 83),
+    'none_h100': (_cfg(1, 100, None, None, None), 33),
+    'one_layer_easy_d2': (_cfg(2, 6, _w(70, 'tanh', 1), _w(18, 'relu', 1), _w(65, 'tanh', 1),
+                               dropout=0.2, which_loss='easy'), 23),
+    'deep_relu_no_residual_current_t': (_cfg(1, 12, _w(24, 'relu', 4), _w(24, 'relu', 4),
+                                             _w(24, 'relu', 4), dropout=0.1, residual_enc_dec=False,
+                                             input_current_t=True), 40),
+}
+
+
+@pytest.mark.parametrize('name', sorted(PLAN_CASES))
+def test_segment_plan_agrees_with_the_lockstep_plan(name, monkeypatch):
+    """Unmasked loss calls run the segment plan (njode_gen_seg.h: one work item per
+    inter-observation segment); NJODE_GEN_PLAN=lock keeps them on the lockstep plan.  Both draw
+    the same dropout masks (keys: seed, global path, Euler step of the event, network, layer,
+    unit), so loss, hT and the gradient agree to rounding -- in train mode, dropout on."""
+    cfg, B = PLAN_CASES[name]
+    torch.manual_seed(11)
+    m = hip_model(cfg).train()
+    b, meta = bs_batch(B, seed=5)
+    if cfg['input_size'] == 2:
+        b['X'] = torch.cat([b['X'], b['X'] ** 2], 1)
+        b['start_X'] = torch.cat([b['start_X'], b['start_X'] ** 2], 1)
+    dt, T = meta['dt'], meta['maturity']
+    out = {}
+    for plan in ('seg', 'lock'):
+        if plan == 'lock':
+            monkeypatch.setenv('NJODE_GEN_PLAN', 'lock')
+        else:
+            monkeypatch.delenv('NJODE_GEN_PLAN', raising=False)
+        m._step_counter = 5
+        _, loss = m.loss_and_grad(*_args(b, dt, T))
+        g = m.flat_grad().clone().cpu().numpy()
+        m._step_counter = 5
+        with torch.no_grad():
+            hT, loss2 = hip_forward(m, b, dt, T + 0.02, until_T=True)      # tails: hT past the last row
+        out[plan] = (float(loss), g, hT.cpu().numpy(), float(loss2))
+    monkeypatch.delenv('NJODE_GEN_PLAN', raising=False)
+    (l_s, g_s, h_s, l2_s), (l_l, g_l, h_l, l2_l) = out['seg'], out['lock']
+    assert l_s == pytest.approx(l_l, rel=2e-6)
+    assert l2_s == pytest.approx(l2_l, rel=2e-6)
+    np.testing.assert_allclose(h_s, h_l, atol=2e-6, rtol=1e-5)
+    assert rel_l2(g_s, g_l) < 2e-6, rel_l2(g_s, g_l)
+    assert np.abs(g_s).max() > 0
