@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnjode_hip.so')
+# (NJODE_LIB: another build of the same library, e.g. the diagnostic build of tools/ubench)
+LIB_PATH = os.environ.get('NJODE_LIB') or os.path.join(_HERE, 'libnjode_hip.so')
 
 # ---- constants mirrored from include/njode_hip.h -----------------------------------
 NJODE_OK = 0

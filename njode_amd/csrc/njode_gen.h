@@ -87,7 +87,13 @@ struct GArgs {
   DropCtx dc;
   float keep, weight;
   int img_rows;          // rows of one ping-pong image
+  int dbg;               // ablation bits of the diagnostic build (-DNJ_GEN_ABL), 0 otherwise
 };
+#ifdef NJ_GEN_ABL
+#define ABL(dbg, bit) ((dbg) & (bit))
+#else
+#define ABL(dbg, bit) 0
+#endif
 
 // ---- LDS carve-up (floats), identical in the forward and the sweep --------------------------
 struct GLds {
@@ -138,66 +144,133 @@ NJ_DEV bool drop_keep(uint32_t base, int layer, int unit, uint32_t thr16) {
   return (h >> 16) >= thr16;
 }
 
-// ---- one matrix product of a tile: acc[t] = A(tile mt0 + t) x in, t < TT --------------------
-// ft: fragment table of the layer ([tile][Qp][64 lanes]); in: LDS image (16 floats per unit)
-template <int TT>
-NJ_DEV void mfma_tiles(const float* __restrict__ ft, int Qp, int mt0, lfp in, int lane, f32x4 (&acc)[TT]) {
-  const int g = lane >> 4, c = lane & 15;
-  const float* fp = ft + (size_t)mt0 * Qp * 64 + lane;
-  lfp bp = in + g * 16 + c;
-  float an[QU][TT];
+// ---- LDS images ------------------------------------------------------------------------------
+// A vector over the tile (unit u, chain c) lives at pix(u * 16 + c): within every block of 16
+// units the four k-steps a lane group needs next to each other are adjacent,
+//   [block u / 16][lane group u % 4][chain][k-step (u / 4) % 4],
+// so the B operands of FOUR MFMAs are one conflict-free ds_read_b128 (lane (g, c) reads the 16
+// bytes at block * 256 + g * 64 + c * 4), and an accumulator register r of lane (g, c) -- unit
+// 16 mt + 4 g + r -- goes to mt * 256 + r * 64 + c * 4 + g: 64 consecutive words per store.
+NJ_DEV int pix(int e) {
+  const int u = e >> 4, c = e & 15;
+  return ((u >> 4) << 8) | ((u & 3) << 6) | (c << 2) | ((u >> 2) & 3);
+}
+NJ_DEV void img_put(lfp img, lfp lin, int rows) {     // image <- linear [unit][chain] vector
+  for (int e = threadIdx.x; e < rows * 16; e += blockDim.x) img[pix(e)] = lin[e];
+}
+NJ_DEV void img_get(lfp lin, lfp img, int rows) {     // linear vector <- image
+  for (int e = threadIdx.x; e < rows * 16; e += blockDim.x) lin[e] = img[pix(e)];
+}
+// rows [0, rows) of an image -> global record rows (linear [unit][16]): one ds_read_b128 and four
+// coalesced 256-byte stores per 4 x 64 values
+NJ_DEV void img_store(float* __restrict__ dst, lfp img, int rows) {
+  const int nf4 = ((rows + 15) >> 4) << 6;
+  for (int j = threadIdx.x; j < nf4; j += blockDim.x) {
+    const f4 v = *(lf4p)(img + (j << 2));
+    const int blk = j >> 6, gi = (j >> 4) & 3, c = j & 15;
 #pragma unroll
-  for (int u = 0; u < QU; ++u)
-#pragma unroll
-    for (int t = 0; t < TT; ++t) an[u][t] = fp[((size_t)t * Qp + u) * 64];
-#pragma unroll
-  for (int t = 0; t < TT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int q0 = 0; q0 < Qp; q0 += QU) {
-    float ac[QU][TT];
-#pragma unroll
-    for (int u = 0; u < QU; ++u)
-#pragma unroll
-      for (int t = 0; t < TT; ++t) ac[u][t] = an[u][t];
-    if (q0 + QU < Qp) {
-#pragma unroll
-      for (int u = 0; u < QU; ++u)
-#pragma unroll
-        for (int t = 0; t < TT; ++t) an[u][t] = fp[((size_t)t * Qp + q0 + QU + u) * 64];
-    }
-#pragma unroll
-    for (int u = 0; u < QU; ++u) {
-      const float b = bp[(q0 + u) * 64];
-#pragma unroll
-      for (int t = 0; t < TT; ++t) acc[t] = mfma4(ac[u][t], b, acc[t]);
+    for (int qq = 0; qq < 4; ++qq) {
+      const int u = (blk << 4) + (qq << 2) + gi;
+      if (u < rows) dst[u * 16 + c] = v[qq];
     }
   }
 }
 
-// all tiles [0, MT) of one product, spread over the workgroup's waves; epi(mt, acc) per tile
-template <class EPI>
-NJ_DEV void layer_product(const float* __restrict__ ft, int Qp, int MT, lfp in, EPI epi) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// ---- one matrix product of the tile ------------------------------------------------------------
+// Fragment table of a layer: [output tile][quad of k-steps][64 lanes][4 k-steps] (k_gen_pack), so a
+// wave's tiles are one contiguous stream of QUADS (16 bytes per lane, 1 KB per wave) which it
+// pulls through a ring of RING quads: the loads of the next block of <= RING quads are issued
+// while the current block multiplies, across tile boundaries.  Ring loads are in program order
+// with clamped addresses instead of guards, so the compiler's vmcnt counting stays exact
+// (s_waitcnt vmcnt(7) in front of every quad of a full block).
+constexpr int RING = 8;
+typedef const f4 __attribute__((address_space(1))) * gf4p;      // global memory, 16 B
+struct FragStream {          // the quads of one wave in one layer (all members wave-uniform)
+  gf4p base;                 // quad n of the stream, lane l: base[n * 64 + l]
+  int Qq;                    // quads per tile
+  int ntl;                   // tiles of this wave
+  int mt0;                   // its first tile
+};
+NJ_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+NJ_DEV FragStream frag_stream(const float* __restrict__ ft, int Qq, int MT) {
+  const int wv = wave_id(), nw = blockDim.x >> 6;
   const int per = (MT + nw - 1) / nw;
-  int mt = wv * per;
-  const int end = mt + per < MT ? mt + per : MT;
-  while (end - mt >= 4) {
-    f32x4 acc[4];
-    mfma_tiles<4>(ft, Qp, mt, in, lane, acc);
+  FragStream s;
+  s.mt0 = wv * per;
+  s.ntl = MT - s.mt0 < per ? MT - s.mt0 : per;
+  if (s.ntl < 0) s.ntl = 0;
+  s.Qq = Qq;
+  s.base = (gf4p)(ft + (size_t)s.mt0 * Qq * 256);
+  return s;
+}
+// first block of a stream -> ring
+NJ_DEV void ring_prime(f4 (&ring)[RING], const FragStream s) {
+  if (s.ntl <= 0) return;
+  const int lane = threadIdx.x & 63;
+  const int v = s.Qq < RING ? s.Qq : RING;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) epi(mt + t, acc[t]);
-    mt += 4;
-  }
-  if (end - mt >= 2) {
-    f32x4 acc[2];
-    mfma_tiles<2>(ft, Qp, mt, in, lane, acc);
-    epi(mt, acc[0]);
-    epi(mt + 1, acc[1]);
-    mt += 2;
-  }
-  if (end - mt >= 1) {
-    f32x4 acc[1];
-    mfma_tiles<1>(ft, Qp, mt, in, lane, acc);
-    epi(mt, acc[0]);
+  for (int i = 0; i < RING; ++i) ring[i] = s.base[(i < v ? i : v - 1) * 64 + lane];
+}
+// all tiles of this wave.  epi(tile, acc) once per tile.  A ring slot is refilled right AFTER the
+// MFMAs that read it (same registers, no copies at the loop end); the B operand of the next quad is
+// read from LDS before the MFMAs of the current one are issued.
+template <class EPI>
+NJ_DEV void layer_product(const FragStream s, lfp in, EPI epi, int dbg = 0) {
+  if (s.ntl <= 0) return;
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  f4 ring[RING];
+  if (!ABL(dbg, 32)) ring_prime(ring, s);
+  else for (int i = 0; i < RING; ++i) ring[i] = f4{0.f, 0.f, 0.f, 0.f};
+  lf4p bp = (lf4p)(in + (g << 6) + (c << 2));          // quad q of the input at bp[q * 64]
+  const int NB = (s.Qq + RING - 1) / RING;               // blocks per tile
+  const int vlast = s.Qq - (NB - 1) * RING;              // quads of a tile's last block
+  for (int t = 0; t < s.ntl; ++t) {
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    gf4p tp = s.base + (size_t)t * s.Qq * 64;
+    f4 bv = bp[0];
+    for (int b = 0; b + 1 < NB; ++b) {                   // full blocks; next block: same tile
+      const int vn = b + 2 < NB ? RING : vlast;
+      gf4p np = tp + (size_t)(b + 1) * RING * 64;
+      lf4p bq = bp + b * RING * 64;
+#pragma unroll
+      for (int i = 0; i < RING; ++i) {
+        const f4 bn = bq[(i + 1) * 64];                  // (i = 7: first quad of the next block)
+        if (!ABL(dbg, 2)) {
+          acc0 = mfma4(ring[i][0], bv[0], acc0);
+          acc1 = mfma4(ring[i][1], bv[1], acc1);
+          acc0 = mfma4(ring[i][2], bv[2], acc0);
+          acc1 = mfma4(ring[i][3], bv[3], acc1);
+        } else {
+          acc0 += bv * ring[i];
+        }
+        if (!ABL(dbg, 4)) ring[i] = np[(i < vn ? i : vn - 1) * 64 + lane];
+        bv = bn;
+      }
+    }
+    {                                                     // last block; next block: next tile
+      const bool more = t + 1 < s.ntl;
+      gf4p np = more ? tp + (size_t)s.Qq * 64 : tp;
+      const int vn = more ? (s.Qq < RING ? s.Qq : RING) : 1;
+      lf4p bq = bp + (NB - 1) * RING * 64;
+#pragma unroll
+      for (int i = 0; i < RING; ++i) {
+        if (i < vlast) {
+          f4 bn = bv;
+          if (i + 1 < vlast) bn = bq[(i + 1) * 64];
+          if (!ABL(dbg, 2)) {
+            acc0 = mfma4(ring[i][0], bv[0], acc0);
+            acc1 = mfma4(ring[i][1], bv[1], acc1);
+            acc0 = mfma4(ring[i][2], bv[2], acc0);
+            acc1 = mfma4(ring[i][3], bv[3], acc1);
+          } else {
+            acc0 += bv * ring[i];
+          }
+          bv = bn;
+        }
+        if (!ABL(dbg, 4)) ring[i] = np[(i < vn ? i : vn - 1) * 64 + lane];    // (no next tile: one quad again)
+      }
+    }
+    epi(s.mt0 + t, acc0 + acc1);
   }
 }
 
@@ -217,41 +290,48 @@ NJ_DEV void gstamp(int slot, unsigned long long& t) {
 #endif
 
 // ---- forward of one network on the tile -----------------------------------------------------
-// `in` holds the n_in input rows; returns the image that holds the n_out output rows.
-// rec != null: the layer inputs are stored to the evaluation record (training calls).
-// dbase: per-chain dropout hash base of this evaluation (lane's chain = lane & 15)
+// `in` holds the n_in input rows AND the constant-1 row behind them (the input builders below
+// write it), complete before the caller's barrier; returns the image that holds the n_out output
+// rows.  One barrier per layer.  rec != null: the layer inputs are stored to the evaluation
+// record (training calls).  dbase: per-chain dropout hash base of this evaluation (lane's chain
+// = lane & 15)
 NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* rec, bool drop,
                        uint32_t dbase) {
-  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
 #ifdef NJ_GEN_STAMPS
   unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
   for (int l = 0; l < N.nl; ++l) {
     const GLayer L = N.l[l];
-    if (tid < 16) in[L.n_in * 16 + tid] = 1.0f;             // bias unit
-    if (rec) {
-      float* dst = rec + (size_t)L.a_row * 16;
-      for (int e = tid; e < L.n_in * 16; e += nth) dst[e] = in[e];
-    }
-    __syncthreads();
-    GSTAMP(4, ts);
     const bool hidden = l + 1 < N.nl;
-    layer_product(a.frag + L.f_off, L.Qp, L.MT, in, [&](int mt, const f32x4& acc) {
+    const FragStream cur = frag_stream(a.frag + L.f_off, L.Qp >> 2, L.MT);
+    if (hidden && tid < 16) other[pix(L.n_out * 16 + tid)] = 1.0f;      // bias unit of the next layer
+    if (rec && !ABL(a.dbg, 8)) img_store(rec + (size_t)L.a_row * 16, in, L.n_in);
+    GSTAMP(4, ts);
+    layer_product(cur, in, [&](int mt, const f32x4& acc) {
+      lfp op = other + (mt << 8) + (c << 2) + g;
+      const int u0 = 16 * mt + 4 * g;
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      // (the four values of a lane are independent: straight-line code so that they interleave)
+      if (hidden && !ABL(a.dbg, 1)) {
+        if (L.act == ACT_TANH) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int u = 16 * mt + 4 * g + r;
-        if (u < L.n_out) {
-          float v = acc[r];
-          if (hidden) {
-            v = act_rt(L.act, v);
-            if (drop) v = drop_keep(dbase, l, u, a.dc.thr16) ? v * a.dc.inv_keep : -0.0f;
-          }
-          other[u * 16 + c] = v;
+          for (int r = 0; r < 4; ++r) v[r] = tanh_acc(v[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        }
+        if (drop) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = drop_keep(dbase, l, u0 + r, a.dc.thr16) ? v[r] * a.dc.inv_keep : -0.0f;
         }
       }
-    });
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (u0 + r < L.n_out) op[r << 6] = v[r];
+    }, a.dbg);
     GSTAMP(5 + (l < 2 ? l : 2), ts);
-    __syncthreads();
+    if (!ABL(a.dbg, 64)) __syncthreads();
     GSTAMP(8, ts);
     lfp t = in; in = other; other = t;
   }
@@ -259,43 +339,77 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
 }
 
 // ---- adjoint of one network evaluation ------------------------------------------------------
-// `din` holds the delta of the network output (n_out rows; zero for chains that take no part).
-// Stores the delta of every layer output to the record (for the weight gradients) and leaves
-// the gradient w.r.t. the network INPUT vector in the returned image (n_in rows), unless
-// !need_input (then the first layer's transposed product is skipped).
+// `din` holds the delta of the network output (n_out rows; zero for chains that take no part),
+// complete before the caller's barrier.  Stores the delta of every layer output to the record
+// (for the weight gradients) and leaves the gradient w.r.t. the network INPUT vector in the
+// returned image (n_in rows), unless !need_input (then the first layer's transposed product is
+// skipped).  The stored activations a layer's epilogue needs (act' and the keep bits) are fetched
+// one layer ahead into registers and placed in the OUTPUT image before the product, whose
+// epilogue then reads and overwrites its own element.
+constexpr int ACT_REGS = 8;
+NJ_DEV void acts_fetch(float (&ar)[ACT_REGS], const float* __restrict__ acts, int n) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+#pragma unroll
+  for (int i = 0; i < ACT_REGS; ++i) {
+    const int e = tid + i * nth;
+    ar[i] = acts[e < n ? e : n - 1];
+  }
+}
+NJ_DEV void acts_place(lfp img, const float (&ar)[ACT_REGS], const float* __restrict__ acts, int n) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+#pragma unroll
+  for (int i = 0; i < ACT_REGS; ++i) {
+    const int e = tid + i * nth;
+    if (e < n) img[pix(e)] = ar[i];
+  }
+  for (int e = tid + ACT_REGS * nth; e < n; e += nth) img[pix(e)] = acts[e];   // (widths > 8 nth / 16)
+}
 NJ_DEV lfp net_backward(const GArgs& a, const GNet& N, lfp din, lfp other, float* rec, bool drop,
                         bool need_input) {
   const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int l_lo = need_input ? 0 : 1;                    // lowest layer whose transposed product runs
+  float ar[ACT_REGS];
+  if (N.nl - 1 >= l_lo && N.nl - 1 > 0) {
+    const GLayer& Lt = N.l[N.nl - 1];
+    acts_fetch(ar, rec + (size_t)Lt.a_row * 16, Lt.n_in * 16);
+  }
   for (int l = N.nl - 1; l >= 0; --l) {
     const GLayer L = N.l[l];
-    {
-      float* dst = rec + (size_t)L.d_row * 16;
-      for (int e = tid; e < L.n_out * 16; e += nth) dst[e] = din[e];
-      // rows up to the padded k range must be finite: they meet zero fragments
-      for (int e = L.n_out * 16 + tid; e < L.QTp * 64; e += nth) din[e] = 0.0f;
+    img_store(rec + (size_t)L.d_row * 16, din, L.n_out);
+    if (l < l_lo) break;
+    // rows up to the padded k range must be finite: they meet zero fragments
+    for (int e = L.n_out * 16 + tid; e < L.QTp * 64; e += nth) din[pix(e)] = 0.0f;
+    const float* acts = rec + (size_t)L.a_row * 16;        // this layer's input = act of layer l-1
+    if (l > 0) acts_place(other, ar, acts, L.n_in * 16);
+    const FragStream cur = frag_stream(a.frag + L.ft_off, L.QTp >> 2, L.MTT);
+    if (l - 1 >= l_lo && l - 1 > 0) {
+      const GLayer& Ln = N.l[l - 1];
+      acts_fetch(ar, rec + (size_t)Ln.a_row * 16, Ln.n_in * 16);
     }
     __syncthreads();
-    if (l == 0 && !need_input) break;
-    const float* acts = rec + (size_t)L.a_row * 16;        // this layer's input = act of layer l-1
     const int pact = l > 0 ? N.l[l - 1].act : -1;
-    layer_product(a.frag + L.ft_off, L.QTp, L.MTT, din, [&](int mt, const f32x4& acc) {
+    layer_product(cur, din, [&](int mt, const f32x4& acc) {
+      lfp op = other + (mt << 8) + (c << 2) + g;
+      const int u0 = 16 * mt + 4 * g;
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      if (l > 0) {
+        float av[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int u = 16 * mt + 4 * g + r;
-        if (u < L.n_in) {
-          float v = acc[r];
-          if (l > 0) {
-            const float av = acts[u * 16 + c];
-            if (drop) {
-              const bool dropped = __float_as_uint(av) == 0x80000000u;
-              v = dropped ? 0.0f : v * a.dc.inv_keep * dact_rt(pact, av * a.keep);
-            } else {
-              v *= dact_rt(pact, av);
-            }
+        for (int r = 0; r < 4; ++r) av[r] = op[r << 6];
+        if (drop) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool dropped = __float_as_uint(av[r]) == 0x80000000u;
+            v[r] = dropped ? 0.0f : v[r] * a.dc.inv_keep * dact_rt(pact, av[r] * a.keep);
           }
-          other[u * 16 + c] = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= dact_rt(pact, av[r]);
         }
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (u0 + r < L.n_in) op[r << 6] = v[r];
     });
     __syncthreads();
     lfp t = din; din = other; other = t;
@@ -307,9 +421,10 @@ NJ_DEV lfp net_backward(const GArgs& a, const GNet& N, lfp din, lfp other, float
 // encoder input [tanh(x) ; mask] into `in` (models.py:261-276: ffnn(cat(tanh(x), mask)))
 NJ_DEV void enc_input(const GArgs& a, lfp in, lfp x, lfp mask) {
   for (int e = threadIdx.x; e < a.D * 16; e += blockDim.x) {
-    in[e] = tanh_acc(x[e]);
-    if (a.masked) in[a.D * 16 + e] = mask[e];
+    in[pix(e)] = tanh_acc(x[e]);
+    if (a.masked) in[pix(a.D * 16 + e)] = mask[e];
   }
+  if (threadIdx.x < 16) in[pix((a.masked ? 2 * a.D : a.D) * 16 + threadIdx.x)] = 1.0f;   // bias unit
 }
 // identity path of the encoder added to its output: out[j] += f(x)   (raw x, models.py:240-259)
 NJ_DEV void enc_residual(const GArgs& a, lfp out, lfp x) {
@@ -327,7 +442,8 @@ NJ_DEV void enc_residual(const GArgs& a, lfp out, lfp x) {
   }
 }
 NJ_DEV void dec_input(const GArgs& a, lfp in, lfp h) {
-  for (int e = threadIdx.x; e < a.H * 16; e += blockDim.x) in[e] = tanh_acc(h[e]);
+  for (int e = threadIdx.x; e < a.H * 16; e += blockDim.x) in[pix(e)] = tanh_acc(h[e]);
+  if (threadIdx.x < 16) in[pix(a.H * 16 + threadIdx.x)] = 1.0f;                            // bias unit
 }
 NJ_DEV void dec_residual(const GArgs& a, lfp out, lfp h) {
   if (a.dec_case == 0) return;
@@ -342,9 +458,6 @@ NJ_DEV void dec_residual(const GArgs& a, lfp out, lfp h) {
     }
     out[e] += s;
   }
-}
-NJ_DEV void copy_rows(lfp dst, lfp src, int rows) {
-  for (int e = threadIdx.x; e < rows * 16; e += blockDim.x) dst[e] = src[e];
 }
 
 // paper loss of the tile's observed chains (models.py:71-126) and its gradients; one thread per
@@ -392,13 +505,14 @@ NJ_DEV void loss_tile(const GArgs& a, lfp x, lfp mask, lfp y, lfp ybj, const int
 NJ_DEV void ode_input(const GArgs& a, lfp in, lfp tx, lfp h, lfp tau, float t) {
   const int n = (a.D + a.H) * 16;
   for (int e = threadIdx.x; e < n; e += blockDim.x)
-    in[e] = e < a.D * 16 ? tx[e] : tanh_acc(h[e - a.D * 16]);
+    in[pix(e)] = e < a.D * 16 ? tx[e] : tanh_acc(h[e - a.D * 16]);
   if (threadIdx.x < 16) {
     const int c = threadIdx.x;
     const float ta = tau[c], td = t - ta;
-    in[(a.D + a.H) * 16 + c] = ta;
-    in[(a.D + a.H + 1) * 16 + c] = td;
-    if (a.curt) in[(a.D + a.H + 2) * 16 + c] = ta + td;
+    in[pix((a.D + a.H) * 16 + c)] = ta;
+    in[pix((a.D + a.H + 1) * 16 + c)] = td;
+    if (a.curt) in[pix((a.D + a.H + 2) * 16 + c)] = ta + td;
+    in[pix(a.IN0 * 16 + c)] = 1.0f;                                                        // bias unit
   }
 }
 
@@ -439,7 +553,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
     float* rec = a.save ? a.rec_enc + ((size_t)a.n_times * a.T + tile) * a.enc.rec_rows * 16 : nullptr;
     lfp out = net_forward(a, a.enc, S.img0, S.img1, rec, a.drop != 0,
                           drop_base(a.dc, gidc, G_TKEY_START, G_NET_ENC));
-    copy_rows(S.h, out, a.H);
+    img_get(S.h, out, a.H);
     __syncthreads();
     enc_residual(a, S.h, S.xr);
     __syncthreads();
@@ -451,7 +565,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
     __syncthreads();
     lfp out = net_forward(a, a.dec, S.img0, S.img1, nullptr, a.drop != 0,
                           drop_base(a.dc, gidc, tkey, G_NET_DEC_ROW));
-    copy_rows(S.y, out, a.DO);
+    img_get(S.y, out, a.DO);
     __syncthreads();
     dec_residual(a, S.y, S.h);
     __syncthreads();
@@ -510,7 +624,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
           float* rec = a.save ? a.rec_dec + (jrec * 2 + 0) * a.dec.rec_rows * 16 : nullptr;
           lfp out = net_forward(a, a.dec, S.img0, S.img1, rec, a.drop != 0,
                                 drop_base(a.dc, gidc, (uint32_t)k, G_NET_DEC_BJ));
-          copy_rows(S.ybj, out, a.DO);
+          img_get(S.ybj, out, a.DO);
           __syncthreads();
           dec_residual(a, S.ybj, S.h);
         }
@@ -543,7 +657,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
           float* rec = a.save ? a.rec_enc + jrec * a.enc.rec_rows * 16 : nullptr;
           lfp out = net_forward(a, a.enc, S.img0, S.img1, rec, a.drop != 0,
                                 drop_base(a.dc, gidc, (uint32_t)k, G_NET_ENC));
-          copy_rows(S.hn, out, a.H);
+          img_get(S.hn, out, a.H);
           __syncthreads();
           enc_residual(a, S.hn, S.xin);
           __syncthreads();
@@ -562,7 +676,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
           // (path output: unobserved chains keep the y of their last row, as the reference's
           // whole-batch readout gives them in eval mode)
           for (int e = tid; e < a.DO * 16; e += nth)
-            if (S.rows[e & 15] >= 0 || !a.want_path) S.y[e] = out[e];
+            if (S.rows[e & 15] >= 0 || !a.want_path) S.y[e] = out[pix(e)];
           __syncthreads();
           for (int e = tid; e < a.DO * 16; e += nth) {
             if (S.rows[e & 15] >= 0 || !a.want_path) {
@@ -612,7 +726,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
       lfp out = net_forward(a, a.ode, S.img0, S.img1, rec, a.drop != 0,
                             drop_base(a.dc, gidc, (uint32_t)k, G_NET_ODE));
       GSTAMP(1, t0);
-      for (int e = tid; e < a.H * 16; e += nth) S.h[e] = fmaf(dt, out[e], S.h[e]);
+      for (int e = tid; e < a.H * 16; e += nth) S.h[e] = fmaf(dt, out[pix(e)], S.h[e]);
       __syncthreads();
       GSTAMP(2, t0);
       emit_row(0x80000000u + (uint32_t)k);
@@ -655,18 +769,18 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
       // ---- reverse Euler step k: h' = h + dt f(in0)
       float* rec = a.rec_ode + ((size_t)k * a.T + tile) * a.ode.rec_rows * 16;
       const float dt = a.step_dt[k];
-      for (int e = tid; e < a.H * 16; e += nth) S.img0[e] = dt * lam_h[e];
+      for (int e = tid; e < a.H * 16; e += nth) S.img0[pix(e)] = dt * lam_h[e];
       __syncthreads();
       lfp din = net_backward(a, a.ode, S.img0, S.img1, rec, drop, true);
       const float* in0 = rec + (size_t)a.ode.l[0].a_row * 16;
       for (int e = tid; e < a.H * 16; e += nth) {
         const float th = in0[a.D * 16 + e];
-        lam_h[e] = fmaf(din[a.D * 16 + e], 1.0f - th * th, lam_h[e]);
+        lam_h[e] = fmaf(din[pix(a.D * 16 + e)], 1.0f - th * th, lam_h[e]);
       }
       if (a.masked) {
         for (int e = tid; e < a.D * 16; e += nth) {
           const float t = in0[e];
-          lam_x[e] = fmaf(din[e], 1.0f - t * t, lam_x[e]);
+          lam_x[e] = fmaf(din[pix(e)], 1.0f - t * t, lam_x[e]);
         }
       }
       __syncthreads();
@@ -702,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
       __syncthreads();
       // y = readout(h_new)
       float* rec_y = a.rec_dec + (jrec * 2 + 1) * a.dec.rec_rows * 16;
-      copy_rows(S.img0, dy, a.DO);
+      img_put(S.img0, dy, a.DO);
       __syncthreads();
       {
         lfp din = net_backward(a, a.dec, S.img0, S.img1, rec_y, drop, true);
@@ -711,7 +825,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
           const int j = e >> 4, c = e & 15;
           if (S.rows[c] >= 0) {
             const float t = th[e];
-            float v = din[e] * (1.0f - t * t);
+            float v = din[pix(e)] * (1.0f - t * t);
             if (a.dec_case == 1) {
               for (int q = j; q < a.DO; q += a.H) v += dy[q * 16 + c];
             } else if (a.dec_case == 2) {
@@ -726,7 +840,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
       }
       // h_new = encoder(x_in, M)
       float* rec_e = a.rec_enc + jrec * a.enc.rec_rows * 16;
-      copy_rows(S.img0, lam_hn, a.H);
+      img_put(S.img0, lam_hn, a.H);
       __syncthreads();
       {
         lfp din = net_backward(a, a.enc, S.img0, S.img1, rec_e, drop, a.masked != 0);
@@ -736,7 +850,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
             const int q = e >> 4, c = e & 15;
             if (S.rows[c] >= 0) {
               const float t = ein[e];
-              float v = din[e] * (1.0f - t * t);
+              float v = din[pix(e)] * (1.0f - t * t);
               if (a.enc_case == 1) {
                 for (int j = q; j < a.H; j += a.D) v += lam_hn[j * 16 + c];
               } else if (a.enc_case == 2) {
@@ -750,7 +864,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
       }
       // y_bj = readout(h_pre): the only path from the state before the jump
       float* rec_b = a.rec_dec + (jrec * 2 + 0) * a.dec.rec_rows * 16;
-      copy_rows(S.img0, dybj, a.DO);
+      img_put(S.img0, dybj, a.DO);
       __syncthreads();
       {
         lfp din = net_backward(a, a.dec, S.img0, S.img1, rec_b, drop, true);
@@ -759,7 +873,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
           const int j = e >> 4, c = e & 15;
           if (S.rows[c] >= 0) {
             const float t = th[e];
-            float v = din[e] * (1.0f - t * t);
+            float v = din[pix(e)] * (1.0f - t * t);
             if (a.dec_case == 1) {
               for (int q = j; q < a.DO; q += a.H) v += dybj[q * 16 + c];
             } else if (a.dec_case == 2) {
@@ -777,7 +891,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
   // ---- start state: h0 = encoder(start_X): its deltas for the weight gradients
   {
     float* rec = a.rec_enc + ((size_t)a.n_times * a.T + tile) * a.enc.rec_rows * 16;
-    copy_rows(S.img0, lam_h, a.H);
+    img_put(S.img0, lam_h, a.H);
     __syncthreads();
     (void)net_backward(a, a.enc, S.img0, S.img1, rec, drop, false);
   }
@@ -803,7 +917,7 @@ struct GDw {
 constexpr int DW_TM = 4, DW_TN = 4;
 __global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
   __shared__ __attribute__((aligned(16))) float red[3 * DW_TM * DW_TN * 4 * 64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, wv = wave_id(), g = lane >> 4, c = lane & 15;
   const int bn = (d.tiles_n + DW_TN - 1) / DW_TN;
   const int tm0 = (blockIdx.x / bn) * DW_TM, tn0 = (blockIdx.x % bn) * DW_TN;
   f32x4 G[DW_TM][DW_TN];
@@ -812,6 +926,8 @@ __global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
 #pragma unroll
     for (int j = 0; j < DW_TN; ++j) G[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long long stride = (long long)gridDim.y * 4;
+  const int nm = d.tiles_m - tm0 < DW_TM ? d.tiles_m - tm0 : DW_TM;     // tiles of this block (uniform)
+  const int nn = d.tiles_n - tn0 < DW_TN ? d.tiles_n - tn0 : DW_TN;
   // operand rows of this lane: clamp to a valid row, zero the value afterwards
   int arow[DW_TM], brow[DW_TN];
   bool aok[DW_TM], bok[DW_TN], bone[DW_TN];
@@ -829,26 +945,54 @@ __global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
     brow[j] = d.a_row + (bok[j] ? u : 0);
   }
   const long long n_rec = d.n_rec_dev ? (long long)d.n_rec_dev[0] : d.n_rec;
-  for (long long r = (long long)blockIdx.y * 4 + wv; r < n_rec; r += stride) {
-    if (d.flags && r < d.n_flagged && !d.flags[r / d.flag_div]) continue;   // wave-uniform
+  // records of this wave: r0, r0 + stride, ...; the operands of the next record are in flight
+  // while the 64 MFMAs of the current one issue (two register sets, no copies)
+  auto next_active = [&](long long r) {
+    while (r < n_rec && d.flags && r < d.n_flagged && !d.flags[r / d.flag_div]) r += stride;   // wave-uniform
+    return r;
+  };
+  auto load = [&](long long r, f4 (&af)[DW_TM], f4 (&bf)[DW_TN]) {
     const float* rec = d.rec + (size_t)r * d.rec_floats;
-    f4 af[DW_TM], bf[DW_TN];
 #pragma unroll
-    for (int i = 0; i < DW_TM; ++i) {
-      af[i] = *(const f4*)(rec + (size_t)arow[i] * 16 + 4 * g);
+    for (int i = 0; i < DW_TM; ++i) af[i] = *(const f4*)(rec + (size_t)arow[i] * 16 + 4 * g);
+#pragma unroll
+    for (int j = 0; j < DW_TN; ++j) bf[j] = *(const f4*)(rec + (size_t)brow[j] * 16 + 4 * g);
+  };
+  auto mm = [&](f4 (&af)[DW_TM], f4 (&bf)[DW_TN]) {
+#pragma unroll
+    for (int i = 0; i < DW_TM; ++i)
       if (!aok[i]) af[i] = f4{0.f, 0.f, 0.f, 0.f};
-    }
 #pragma unroll
-    for (int j = 0; j < DW_TN; ++j) {
-      bf[j] = *(const f4*)(rec + (size_t)brow[j] * 16 + 4 * g);
+    for (int j = 0; j < DW_TN; ++j)
       if (!bok[j]) bf[j] = bone[j] ? f4{1.f, 1.f, 1.f, 1.f} : f4{0.f, 0.f, 0.f, 0.f};
-    }
+    // (tiles beyond the layer's edge are skipped: a narrow first / last layer has one tile column / row)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < DW_TM; ++i)
+        if (i < nm) {
 #pragma unroll
-        for (int j = 0; j < DW_TN; ++j) G[i][j] = mfma4(af[i][s], bf[j][s], G[i][j]);
+          for (int j = 0; j < DW_TN; ++j)
+            if (j < nn) G[i][j] = mfma4(af[i][s], bf[j][s], G[i][j]);
+        }
+  };
+  long long r = next_active((long long)blockIdx.y * 4 + wv);
+  if (r < n_rec) {
+    f4 a0[DW_TM], b0[DW_TN], a1[DW_TM], b1[DW_TN];
+    load(r, a0, b0);
+    for (;;) {
+      const long long r1 = next_active(r + stride);
+      const bool h1 = r1 < n_rec;
+      load(h1 ? r1 : r, a1, b1);          // (no next record: the same one again, not used)
+      mm(a0, b0);
+      if (!h1) break;
+      const long long r2 = next_active(r1 + stride);
+      const bool h2 = r2 < n_rec;
+      load(h2 ? r2 : r1, a0, b0);
+      mm(a1, b1);
+      if (!h2) break;
+      r = r2;
+    }
   }
   // the four waves of the block add their tiles in fixed order -> one slab row per blockIdx.y
   f32x4 __attribute__((address_space(3)))* rd = (f32x4 __attribute__((address_space(3)))*)(lfp)red;
@@ -890,7 +1034,9 @@ __global__ void k_gen_pack(const float* __restrict__ P, float* __restrict__ frag
     const GLayer L = p.l[q];
     const int nf = L.MT * L.Qp * 64, nt = L.MTT * L.QTp * 64;
     if (idx >= L.f_off && idx < L.f_off + nf) {
-      const int e = idx - L.f_off, lane = e & 63, f = e >> 6, mt = f / L.Qp, k = f % L.Qp;
+      // [tile][quad][lane][k-step of the quad]
+      const int e = idx - L.f_off, qq = e & 3, lane = (e >> 2) & 63, f = e >> 8, Qq = L.Qp >> 2;
+      const int mt = f / Qq, k = 4 * (f % Qq) + qq;
       const int o = 16 * mt + (lane & 15), i = 4 * k + (lane >> 4);
       float v = 0.0f;
       if (o < L.n_out) v = i < L.n_in ? P[L.w_off + (size_t)o * L.n_in + i] : (i == L.n_in ? P[L.b_off + o] : 0.0f);
@@ -898,7 +1044,8 @@ __global__ void k_gen_pack(const float* __restrict__ P, float* __restrict__ frag
       return;
     }
     if (idx >= L.ft_off && idx < L.ft_off + nt) {
-      const int e = idx - L.ft_off, lane = e & 63, f = e >> 6, mt = f / L.QTp, k = f % L.QTp;
+      const int e = idx - L.ft_off, qq = e & 3, lane = (e >> 2) & 63, f = e >> 8, Qq = L.QTp >> 2;
+      const int mt = f / Qq, k = 4 * (f % Qq) + qq;
       const int i = 16 * mt + (lane & 15), o = 4 * k + (lane >> 4);
       frag[idx] = (i < L.n_in && o < L.n_out) ? P[L.w_off + (size_t)o * L.n_in + i] : 0.0f;
       return;

@@ -408,6 +408,9 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
   a.keep = 1.0f - (float)a.dc.thr16 / 65536.0f;
   a.dc.inv_keep = 1.0f / a.keep;
   a.weight = weight;
+#ifdef NJ_GEN_ABL
+  a.dbg = getenv("NJODE_GEN_DBG") ? atoi(getenv("NJODE_GEN_DBG")) : 0;
+#endif
   memset(&c.g, 0, sizeof(c.g));
   if (c.L.seg) {
     GSeg& g = c.g;

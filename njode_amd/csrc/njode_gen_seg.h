@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(1024) k_gseg_enc(GArgs a, GSeg g) {
                                    start ? G_TKEY_START : (uint32_t)keyI[cch], G_NET_ENC);
   float* rec = a.save ? a.rec_enc + (size_t)tile * a.enc.rec_rows * 16 : nullptr;
   lfp out = net_forward(a, a.enc, S.img0, S.img1, rec, a.drop != 0, dbase);
-  copy_rows(S.h, out, a.H);
+  img_get(S.h, out, a.H);
   __syncthreads();
   enc_residual(a, S.h, S.xr);
   __syncthreads();
@@ -156,30 +156,43 @@ NJ_DEV void seg_tile_setup(const GArgs& a, const GSeg& g, GLds& S, SegTile& t, i
   for (int c = 0; c < 16; ++c) m = t.len[c] > m ? t.len[c] : m;
   t.maxlen = m;
 }
-// time and step size of every chain at local step s (inactive chains: dt = 0); dt goes to one of
-// two slots (s & 1) so that the values of step s + 1 can be written while step s still reads its own
-NJ_DEV void seg_step_times(const GArgs& a, const SegTile& t, int s) {
+// time and step size of every chain at local step s (inactive chains: dt = 0), fetched into
+// registers of the first 16 threads one step before they are published in LDS; dt goes to one
+// of two slots (s & 1) so that the values of step s + 1 can be written while step s still reads
+// its own
+struct SegClock { float t, dt; };
+NJ_DEV SegClock seg_clock_fetch(const GArgs& a, const SegTile& t, int s) {
+  SegClock c{0.0f, 0.0f};
   const int tid = threadIdx.x;
-  if (tid < 16 && s >= 0) {
+  if (tid < 16 && s >= 0 && a.K > 0) {
     int k = t.kbeg[tid] + s;
     const bool on = s < t.len[tid];
     if (k > a.K - 1) k = a.K - 1;
     if (k < 0) k = 0;
-    t.tcur[tid] = a.K > 0 ? a.step_t[k] : 0.0f;
-    t.dtc[(s & 1) * 16 + tid] = (on && a.K > 0) ? a.step_dt[k] : 0.0f;
+    c.t = a.step_t[k];
+    c.dt = on ? a.step_dt[k] : 0.0f;
+  }
+  return c;
+}
+NJ_DEV void seg_clock_put(const SegTile& t, int s, const SegClock c) {
+  const int tid = threadIdx.x;
+  if (tid < 16 && s >= 0) {
+    t.tcur[tid] = c.t;
+    t.dtc[(s & 1) * 16 + tid] = c.dt;
   }
 }
 // ODE input with a time per chain (ode_input of njode_gen.h takes one time for the tile)
 NJ_DEV void seg_ode_input(const GArgs& a, lfp in, lfp tx, lfp h, lfp tau, lfp tcur) {
   const int n = (a.D + a.H) * 16;
   for (int e = threadIdx.x; e < n; e += blockDim.x)
-    in[e] = e < a.D * 16 ? tx[e] : tanh_acc(h[e - a.D * 16]);
+    in[pix(e)] = e < a.D * 16 ? tx[e] : tanh_acc(h[e - a.D * 16]);
   if (threadIdx.x < 16) {
     const int c = threadIdx.x;
     const float ta = tau[c], td = tcur[c] - ta;
-    in[(a.D + a.H) * 16 + c] = ta;
-    in[(a.D + a.H + 1) * 16 + c] = td;
-    if (a.curt) in[(a.D + a.H + 2) * 16 + c] = ta + td;
+    in[pix((a.D + a.H) * 16 + c)] = ta;
+    in[pix((a.D + a.H + 1) * 16 + c)] = td;
+    if (a.curt) in[pix((a.D + a.H + 2) * 16 + c)] = ta + td;
+    in[pix(a.IN0 * 16 + c)] = 1.0f;                          // bias unit
   }
 }
 
@@ -208,7 +221,8 @@ __global__ void __launch_bounds__(1024) k_gseg_ode_fwd(GArgs a, GSeg g) {
     if (t.row[c] >= 0) v = t.prev[c] >= 0 ? a.X[(size_t)t.prev[c] * a.D + q] : a.start_X[(size_t)t.path[c] * a.D + q];
     S.tx[q * 16 + c] = tanh_acc(v);
   }
-  seg_step_times(a, t, 0);
+  seg_clock_put(t, 0, seg_clock_fetch(a, t, 0));
+  SegClock nclk = seg_clock_fetch(a, t, 1);
   __syncthreads();
   const int cch = tid & 15;
   const unsigned long long gidc = a.gid0 + (unsigned long long)t.path[cch];
@@ -216,18 +230,27 @@ __global__ void __launch_bounds__(1024) k_gseg_ode_fwd(GArgs a, GSeg g) {
   const bool save = a.save && !tail;
   const size_t rbase = save ? (size_t)g.tile_base[tile] : 0;
   for (int s = 0; s < t.maxlen; ++s) {
-    seg_ode_input(a, S.img0, S.tx, S.h, t.tau, t.tcur);
-    __syncthreads();
-    seg_step_times(a, t, s + 1);   // (tcur of step s was consumed above; dt goes to the other slot)
+#ifdef NJ_GEN_STAMPS
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && tid == 0) g_gen_stamps[15] += 1;
+#endif
+    if (!ABL(a.dbg, 16)) seg_ode_input(a, S.img0, S.tx, S.h, t.tau, t.tcur);
+    if (!ABL(a.dbg, 64)) __syncthreads();
+    GSTAMP(0, t0);
+    seg_clock_put(t, s + 1, nclk);   // (tcur of step s was consumed above; dt goes to the other slot)
+    nclk = seg_clock_fetch(a, t, s + 2);
     float* rec = save ? a.rec_ode + (rbase + s) * a.ode.rec_rows * 16 : nullptr;
     lfp out = net_forward(a, a.ode, S.img0, S.img1, rec, a.drop != 0,
                           drop_base(a.dc, gidc, kb + (uint32_t)s, G_NET_ODE));
+    GSTAMP(1, t0);
     lfp dts = t.dtc + (s & 1) * 16;
-    for (int e = tid; e < a.H * 16; e += nth) {
-      const float dt = dts[e & 15];
-      if (dt != 0.0f) S.h[e] = fmaf(dt, out[e], S.h[e]);
-    }
-    __syncthreads();
+    if (!ABL(a.dbg, 16))
+      for (int e = tid; e < a.H * 16; e += nth) {
+        const float dt = dts[e & 15];
+        if (dt != 0.0f) S.h[e] = fmaf(dt, out[pix(e)], S.h[e]);
+      }
+    if (!ABL(a.dbg, 64)) __syncthreads();
+    GSTAMP(2, t0);
   }
   store_rows(tail ? a.hT : g.h_end, S.h, t.row, a.H);
 }
@@ -268,7 +291,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
   __syncthreads();
   {
     lfp out = net_forward(a, a.dec, S.img0, S.img1, rec_b, a.drop != 0, drop_base(a.dc, gidc, tk, G_NET_DEC_BJ));
-    copy_rows(S.ybj, out, a.DO);
+    img_get(S.ybj, out, a.DO);
     __syncthreads();
     dec_residual(a, S.ybj, S.h);
     __syncthreads();
@@ -278,7 +301,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
   __syncthreads();
   {
     lfp out = net_forward(a, a.dec, S.img0, S.img1, rec_y, a.drop != 0, drop_base(a.dc, gidc, tk, G_NET_DEC));
-    copy_rows(S.y, out, a.DO);
+    img_get(S.y, out, a.DO);
     __syncthreads();
     dec_residual(a, S.y, S.hn);
     __syncthreads();
@@ -290,7 +313,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
   if (!a.save) return;
   const bool drop = a.drop != 0;
   // adjoint of y = readout(h0row): gradient at the start of the next item
-  copy_rows(S.img0, dy, a.DO);
+  img_put(S.img0, dy, a.DO);
   __syncthreads();
   {
     lfp din = net_backward(a, a.dec, S.img0, S.img1, rec_y, drop, true);
@@ -298,7 +321,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
     for (int e = tid; e < a.H * 16; e += nth) {
       const int j = e >> 4, c = e & 15;
       const float tv = th[e];
-      float v = din[e] * (1.0f - tv * tv);
+      float v = din[pix(e)] * (1.0f - tv * tv);
       if (a.dec_case == 1) {
         for (int q = j; q < a.DO; q += a.H) v += dy[q * 16 + c];
       } else if (a.dec_case == 2) {
@@ -310,7 +333,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
     store_rows(g.g_h0, S.hn, ids, a.H);
   }
   // adjoint of y_bj = readout(h_end): gradient at the end of the item
-  copy_rows(S.img0, dybj, a.DO);
+  img_put(S.img0, dybj, a.DO);
   __syncthreads();
   {
     lfp din = net_backward(a, a.dec, S.img0, S.img1, rec_b, drop, true);
@@ -318,7 +341,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
     for (int e = tid; e < a.H * 16; e += nth) {
       const int j = e >> 4, c = e & 15;
       const float tv = th[e];
-      float v = din[e] * (1.0f - tv * tv);
+      float v = din[pix(e)] * (1.0f - tv * tv);
       if (a.dec_case == 1) {
         for (int q = j; q < a.DO; q += a.H) v += dybj[q * 16 + c];
       } else if (a.dec_case == 2) {
@@ -346,19 +369,21 @@ __global__ void __launch_bounds__(1024) k_gseg_ode_bwd(GArgs a, GSeg g) {
   const bool drop = a.drop != 0;
   const size_t rbase = (size_t)g.tile_base[tile];
   __syncthreads();
-  seg_step_times(a, t, t.maxlen - 1);
+  seg_clock_put(t, t.maxlen - 1, seg_clock_fetch(a, t, t.maxlen - 1));
+  SegClock nclk = seg_clock_fetch(a, t, t.maxlen - 2);
   __syncthreads();
   for (int s = t.maxlen - 1; s >= 0; --s) {
     float* rec = a.rec_ode + (rbase + s) * a.ode.rec_rows * 16;
     lfp dts = t.dtc + (s & 1) * 16;
-    for (int e = tid; e < a.H * 16; e += nth) S.img0[e] = dts[e & 15] * lam[e];
+    for (int e = tid; e < a.H * 16; e += nth) S.img0[pix(e)] = dts[e & 15] * lam[e];
     __syncthreads();
-    seg_step_times(a, t, s - 1);
+    seg_clock_put(t, s - 1, nclk);
+    nclk = seg_clock_fetch(a, t, s - 2);
     lfp din = net_backward(a, a.ode, S.img0, S.img1, rec, drop, true);
     const float* in0 = rec + (size_t)a.ode.l[0].a_row * 16;
     for (int e = tid; e < a.H * 16; e += nth) {
       const float th = in0[a.D * 16 + e];
-      lam[e] = fmaf(din[a.D * 16 + e], 1.0f - th * th, lam[e]);
+      lam[e] = fmaf(din[pix(a.D * 16 + e)], 1.0f - th * th, lam[e]);
     }
     __syncthreads();
   }
@@ -389,7 +414,7 @@ __global__ void __launch_bounds__(1024) k_gseg_enc_bwd(GArgs a, GSeg g) {
     float v = 0.0f;
     if (ids[c] >= 0) v = g.g_h0[(size_t)ids[c] * a.H + j];
     if (nxt[c] >= 0) v += g.lam_start[(size_t)nxt[c] * a.H + j];
-    S.img0[j * 16 + c] = v;
+    S.img0[pix(j * 16 + c)] = v;
   }
   __syncthreads();
   float* rec = a.rec_enc + (size_t)tile * a.enc.rec_rows * 16;

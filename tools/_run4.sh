@@ -1,0 +1,3 @@
+#!/bin/bash
+mkdir -p gpurun_out/r3d
+NJODE_LIB=$PWD/tools/ubench/libnjode_hip_abl.so timeout 600 python tools/ubench/gen_ablate.py 2>/dev/null | tee gpurun_out/r3d/ablate.jsonl

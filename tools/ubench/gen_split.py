@@ -12,7 +12,7 @@ cfg = dict(input_size=1, hidden_size=10, output_size=1, ode_nn=nn, readout_nn=nn
            bias=True, dropout_rate=0.0, options={'device_outputs': True})
 with contextlib.redirect_stdout(sys.stderr):
     m = models.NJODE(**cfg).cuda().eval()
-for p in (0.0005, 0.1, 1.0):
+for p in (0.0005, 0.1):
     b, meta = bs_batch(100, seed=1, obs_perc=p)
     args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'], meta['maturity'],
             b['start_X'].cuda(), b['n_obs_ot'].clamp(min=1).cuda().int())
@@ -33,6 +33,9 @@ for p in (0.0005, 0.1, 1.0):
         buf = (ctypes.c_uint64 * 16)()
         L.njode_gen_debug_stamps(buf)
         n_ev = 13 * 100                            # 13 calls x 100 Euler steps (ODE-step stamps)
+        if buf[15]:                                # segment plan: steps of block 0 (the longest tile), counted
+            n_ev = int(buf[15])
+            rec['steps_of_block0_per_call'] = n_ev / 13
         names = {0: 'ode_input+sync', 1: 'net_forward', 2: 'update+sync', 4: 'layer: bias/rec/sync',
                  5: 'layer0 product', 6: 'layer1 product', 7: 'layer2 product', 8: 'layer: end sync'}
         rec['cycles_per_euler_step'] = {names[i]: round(buf[i] / n_ev) for i in names}
