@@ -164,6 +164,10 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
   m.lds_bytes = gen_lds_floats(a.img_rows, D, H, DO) * 4;
   if (m.lds_bytes > LDS_LIMIT) { *why = "layer images exceed the 160 KB LDS"; return false; }
   m.nw = max_mt < 4 ? 4 : (max_mt > 16 ? 16 : max_mt);
+  if (const char* e = getenv("NJODE_GEN_NW")) {        // experiments: waves per workgroup
+    const int v = atoi(e);
+    if (v >= 1 && v <= 16) m.nw = v;
+  }
   m.S = 2048 / max_tb;
   if (m.S < 8) m.S = 8;
   if (m.S > 256) m.S = 256;
@@ -413,6 +417,19 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
 #endif
   memset(&c.g, 0, sizeof(c.g));
   if (c.L.seg) {
+    // Waves per workgroup: one wave per output tile of the widest layer fills a CU with a single
+    // tile and is the fastest way through ONE tile; when the grid holds many times more tiles than
+    // fit on the chip at once, four waves per tile (each walks several output tiles) run four
+    // tiles per CU and pay the per-wave, per-layer scalar work a quarter as often
+    // (profiles/r03_generic_waves_per_tile.txt: width 100, 20 000 paths: 8.0 -> 5.8 ms).
+    static const int n_cu = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+        v = 256;
+      return v;
+    }();
+    if (!getenv("NJODE_GEN_NW") && c.m.nw > 4 && (long long)c.L.NT >= 16LL * n_cu) c.m.nw = 4;
     GSeg& g = c.g;
     g.order = (const int*)(pw + c.L.order);
     g.item_prev = (const int*)(pw + c.L.item_prev);
