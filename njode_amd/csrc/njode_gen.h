@@ -8,16 +8,19 @@
 // not, every residual case, dropout.  It serves every shape the build table has no
 // specialisation for (reference grids: widths 80 ... 400, nn_desc = None with hidden_size 50 /
 // 100, the climate shape d = 5: NJODE/parallel_train.py:304-305, 366-371, 433-470, 609, 650,
-// 712), on the lockstep plan (one chain per path over the shared grid, models.py:430-511).
+// 712).  Masked models, return_path and get_loss = False run the lockstep plan of this file (one
+// chain per path over the shared grid, models.py:430-511); unmasked loss calls run the segment
+// plan of njode_gen_seg.h on the same building blocks.
 //
 // Execution model
-//   * one workgroup (NW waves) advances a TILE of 16 paths; vectors over the tile live in LDS
-//     images img[unit][chain] (16 floats = one 64-byte row per unit);
+//   * one workgroup (NW waves) advances a TILE of 16 chains; vectors over the tile live in LDS
+//     images (layout: pix() below);
 //   * a layer is out = W in: the A operand (16 output units x 4 input units) streams from a
 //     packed fragment table in global memory (L2-resident: every workgroup reads the same
-//     table), the B operand (4 input units x 16 chains) is one ds_read_b32 of the input image,
-//     wave w owns the output tiles [w per, (w + 1) per); bias = the constant-1 row behind the
-//     inputs; the epilogue applies activation + dropout and writes the output image;
+//     table) through a ring of registers, the B operands (4 input units x 16 chains) of four
+//     k-steps are one ds_read_b128 of the input image, wave w owns the output tiles
+//     [w per, (w + 1) per); bias = the constant-1 row behind the inputs; the epilogue applies
+//     activation + dropout and writes the output image;
 //   * training calls store every layer input of every network evaluation (one record per
 //     (Euler step | jump time, tile)); the adjoint sweep walks the events in reverse with the
 //     transposed fragment tables and stores the delta of every layer output next to it;
