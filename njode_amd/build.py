@@ -15,6 +15,7 @@ import concurrent.futures
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -79,6 +80,9 @@ _RES_KEYS = {'VGPRs': 'vgpr', 'AGPRs': 'agpr', 'SGPRs': 'sgpr', 'ScratchSize [by
              'VGPRs Spill': 'vgpr_spill', 'SGPRs Spill': 'sgpr_spill'}
 
 
+_SNIPPET = re.compile(r'^\s*\d+\s*\|')     # source snippet lines of a remark ('  415 | {')
+
+
 def _parse_resources(out):
     """(kernel -> resources, the rest of the compiler output) from -Rpass-analysis remarks."""
     res, rest, cur = {}, [], None
@@ -97,6 +101,7 @@ def _parse_resources(out):
                     except ValueError:
                         pass
         elif line.strip() and not line.lstrip().startswith(('|', '^', 'In file included from')) \
+                and not _SNIPPET.match(line) \
                 and '__global__' not in line and 'remarks generated' not in line:
             rest.append(line)
     return res, '\n'.join(rest)

@@ -351,6 +351,14 @@ template <class C> struct OdeBwdActLds {
   static constexpr int RED = 3 * NG * 64 * 4;      // the block's final tile reduction
   static constexpr int FLOATS = BODY > RED ? BODY : RED;
 };
+// (-DNJ_BWD_ABL=bits, tools/ubench/bwd_ablate.sh: parts of the Euler-step loop switched off for
+// timing -- 1 weight-gradient products, 2 transposed products, 4 wave-level LDS syncs, 8 the loads
+// of the next step, 16 image writes, 32 act' multiplies, 64 the whole Euler-step loop, 128 the
+// tile reduction and slab flush; the product build has none of it)
+#ifndef NJ_BWD_ABL
+#define NJ_BWD_ABL 0
+#endif
+#define BWD_ABL(bit) ((NJ_BWD_ABL) & (bit))
 template <class C, bool DROP>
 NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
                             int slab_row) {
@@ -398,7 +406,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
       lam[q] = (valid && u < C::H) ? v : 0.0f;
     }
-    const int nmax = wave_max(it.n);
+    const int nmax = BWD_ABL(64) ? 0 : wave_max(it.n);
     // checkpoint, activations and scalars of a step are loaded while the previous one runs
     auto fetch = [&](int s, float (&hh)[M::QH], float (&x1)[M::Q1], float (&x2)[M::Q1], float& dtt,
                      float& tt) {
@@ -428,7 +436,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
       for (int q = 0; q < M::Q1; ++q) { a1[q] = a1_n[q]; a2[q] = a2_n[q]; }
       const float dt = dt_n, t = t_n;
-      if (s > 0) fetch(s - 1, h_n, a1_n, a2_n, dt_n, t_n);
+      if (s > 0 && !BWD_ABL(8)) fetch(s - 1, h_n, a1_n, a2_n, dt_n, t_n);
       float b0[M::Q0];
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
       F.begin();
@@ -437,51 +445,73 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       float d3[M::QH];
 #pragma unroll
       for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
-      img_write<M::QH>(img_d, d3, g, c);
-      img_write<M::Q1>(img_a, a2, g, c);
-      wave_lds_sync();
-      dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
+      if (!BWD_ABL(16)) {
+        img_write<M::QH>(img_d, d3, g, c);
+        img_write<M::Q1>(img_a, a2, g, c);
+      }
+      if (!BWD_ABL(4)) wave_lds_sync();
+      if (!BWD_ABL(1)) dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
       f32x4 acc[M::MT1];
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+      if (!BWD_ABL(2)) {
 #pragma unroll
-      for (int q = 0; q < M::QH; ++q)
+        for (int q = 0; q < M::QH; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
+          for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt][0] = d3[0];
+      }
       float d2[M::QW];
 #pragma unroll
-      for (int q = 0; q < M::QW; ++q) d2[q] = acc[q / 4][q % 4] * dact_stored<C::ACT, DROP>(a2[q]);
-      wave_lds_sync();
+      for (int q = 0; q < M::QW; ++q)
+        d2[q] = acc[q / 4][q % 4] * (BWD_ABL(32) ? 1.0f : dact_stored<C::ACT, DROP>(a2[q]));
+      if (!BWD_ABL(4)) wave_lds_sync();
 
       // ---- layer 2
-      img_write<M::QW>(img_d, d2, g, c);
-      img_write<M::Q1>(img_a, a1, g, c);
-      wave_lds_sync();
-      dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
+      if (!BWD_ABL(16)) {
+        img_write<M::QW>(img_d, d2, g, c);
+        img_write<M::Q1>(img_a, a1, g, c);
+      }
+      if (!BWD_ABL(4)) wave_lds_sync();
+      if (!BWD_ABL(1)) dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
+      if (!BWD_ABL(2)) {
 #pragma unroll
-      for (int q = 0; q < M::QW; ++q)
+        for (int q = 0; q < M::QW; ++q)
 #pragma unroll
-        for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
+          for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < M::MT1; ++mt) acc[mt][0] = d2[mt];
+      }
       float d1[M::QW];
 #pragma unroll
-      for (int q = 0; q < M::QW; ++q) d1[q] = acc[q / 4][q % 4] * dact_stored<C::ACT, DROP>(a1[q]);
-      wave_lds_sync();
+      for (int q = 0; q < M::QW; ++q)
+        d1[q] = acc[q / 4][q % 4] * (BWD_ABL(32) ? 1.0f : dact_stored<C::ACT, DROP>(a1[q]));
+      if (!BWD_ABL(4)) wave_lds_sync();
 
       // ---- layer 1
-      img_write<M::QW>(img_d, d1, g, c);
-      img_write<M::Q0>(img_a, b0, g, c);
-      wave_lds_sync();
-      dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
+      if (!BWD_ABL(16)) {
+        img_write<M::QW>(img_d, d1, g, c);
+        img_write<M::Q0>(img_a, b0, g, c);
+      }
+      if (!BWD_ABL(4)) wave_lds_sync();
+      if (!BWD_ABL(1)) dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
       f32x4 acch[M::MTH];
 #pragma unroll
       for (int mt = 0; mt < M::MTH; ++mt) {
         f32x4 e = zero4, o = zero4;
+        if (!BWD_ABL(2)) {
 #pragma unroll
-        for (int q = 0; q < M::QW; q += 2) {
-          e = mfma4(F.b1(mt, q), d1[q], e);
-          if (q + 1 < M::QW) o = mfma4(F.b1(mt, q + 1), d1[q + 1], o);
+          for (int q = 0; q < M::QW; q += 2) {
+            e = mfma4(F.b1(mt, q), d1[q], e);
+            if (q + 1 < M::QW) o = mfma4(F.b1(mt, q + 1), d1[q + 1], o);
+          }
+        } else {
+          e[0] = d1[0];
         }
         acch[mt] = e + o;
       }
@@ -492,7 +522,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
         const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
         lam[q] = fmaf(acch[q / 4][q % 4], dth, lam[q]);
       }
-      wave_lds_sync();
+      if (!BWD_ABL(4)) wave_lds_sync();
     }
     float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
 #pragma unroll
@@ -503,6 +533,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     }
   }
 
+  if (BWD_ABL(128)) return;
   // ---- flush (as ode_bwd_single): one slab row per block
   constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
   static_assert(3 * NG * 64 * 4 <= OdeBwdActLds<C>::FLOATS, "tile reduction does not fit the LDS");
