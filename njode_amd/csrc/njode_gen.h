@@ -51,6 +51,7 @@ struct GLayer {
   int Qp, MT;           // forward: k-steps (inputs + bias, padded to QU), output tiles of 16
   int QTp, MTT;         // transposed: k-steps over the outputs (padded), tiles over the inputs
   int a_row, d_row;     // record rows: this layer's INPUT vector / the delta of its OUTPUT
+  int per, pert;        // output tiles per wave of the launch: forward / transposed product
 };
 struct GNet {
   int nl;               // layers = hidden layers + 1
@@ -181,12 +182,10 @@ NJ_DEV void img_store(float* __restrict__ dst, lfp img, int rows) {
 
 // ---- one matrix product of the tile ------------------------------------------------------------
 // Fragment table of a layer: [output tile][quad of k-steps][64 lanes][4 k-steps] (k_gen_pack), so a
-// wave's tiles are one contiguous stream of QUADS (16 bytes per lane, 1 KB per wave) which it
-// pulls through a ring of RING quads: the loads of the next block of <= RING quads are issued
-// while the current block multiplies, across tile boundaries.  Ring loads are in program order
-// with clamped addresses instead of guards, so the compiler's vmcnt counting stays exact
-// (s_waitcnt vmcnt(7) in front of every quad of a full block).
-constexpr int RING = 8;
+// wave's tiles are one contiguous stream of QUADS (16 bytes per lane, 1 KB per wave), read RING
+// quads at a time.
+constexpr int RING = 8;     // quads of a short row (no prefetch)
+constexpr int LCH = 4;      // quads per chunk of a long row (two register sets)
 typedef const f4 __attribute__((address_space(1))) * gf4p;      // global memory, 16 B
 struct FragStream {          // the quads of one wave in one layer (all members wave-uniform)
   gf4p base;                 // quad n of the stream, lane l: base[n * 64 + l]
@@ -195,9 +194,8 @@ struct FragStream {          // the quads of one wave in one layer (all members 
   int mt0;                   // its first tile
 };
 NJ_DEV int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-NJ_DEV FragStream frag_stream(const float* __restrict__ ft, int Qq, int MT) {
-  const int wv = wave_id(), nw = blockDim.x >> 6;
-  const int per = (MT + nw - 1) / nw;
+NJ_DEV FragStream frag_stream(const float* __restrict__ ft, int Qq, int MT, int per) {
+  const int wv = wave_id();
   FragStream s;
   s.mt0 = wv * per;
   s.ntl = MT - s.mt0 < per ? MT - s.mt0 : per;
@@ -206,72 +204,83 @@ NJ_DEV FragStream frag_stream(const float* __restrict__ ft, int Qq, int MT) {
   s.base = (gf4p)(ft + (size_t)s.mt0 * Qq * 256);
   return s;
 }
-// first block of a stream -> ring
-NJ_DEV void ring_prime(f4 (&ring)[RING], const FragStream s) {
-  if (s.ntl <= 0) return;
-  const int lane = threadIdx.x & 63;
-  const int v = s.Qq < RING ? s.Qq : RING;
-#pragma unroll
-  for (int i = 0; i < RING; ++i) ring[i] = s.base[(i < v ? i : v - 1) * 64 + lane];
-}
-// all tiles of this wave.  epi(tile, acc) once per tile.  A ring slot is refilled right AFTER the
-// MFMAs that read it (same registers, no copies at the loop end); the B operand of the next quad is
-// read from LDS before the MFMAs of the current one are issued.
+// all tiles of this wave.  epi(tile, acc) once per tile.
 template <class EPI>
 NJ_DEV void layer_product(const FragStream s, lfp in, EPI epi, int dbg = 0) {
   if (s.ntl <= 0) return;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  f4 ring[RING];
-  if (!ABL(dbg, 32)) ring_prime(ring, s);
-  else for (int i = 0; i < RING; ++i) ring[i] = f4{0.f, 0.f, 0.f, 0.f};
-  lf4p bp = (lf4p)(in + (g << 6) + (c << 2));          // quad q of the input at bp[q * 64]
-  const int NB = (s.Qq + RING - 1) / RING;               // blocks per tile
-  const int vlast = s.Qq - (NB - 1) * RING;              // quads of a tile's last block
-  for (int t = 0; t < s.ntl; ++t) {
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    gf4p tp = s.base + (size_t)t * s.Qq * 64;
-    f4 bv = bp[0];
-    for (int b = 0; b + 1 < NB; ++b) {                   // full blocks; next block: same tile
-      const int vn = b + 2 < NB ? RING : vlast;
-      gf4p np = tp + (size_t)(b + 1) * RING * 64;
-      lf4p bq = bp + b * RING * 64;
+  if (s.Qq <= RING) {
+    // short rows (<= 8 quads = 128 input units): the whole tile's fragments at once, no ring --
+    // a fraction of the ring's bookkeeping instructions, and the same one L2 round trip per tile
+    lf4p bq = (lf4p)(in + (g << 6) + (c << 2));
+    for (int t = 0; t < s.ntl; ++t) {
+      gf4p tp = s.base + (size_t)t * s.Qq * 64 + lane;
+      f4 fr[RING];
 #pragma unroll
-      for (int i = 0; i < RING; ++i) {
-        const f4 bn = bq[(i + 1) * 64];                  // (i = 7: first quad of the next block)
-        if (!ABL(dbg, 2)) {
-          acc0 = mfma4(ring[i][0], bv[0], acc0);
-          acc1 = mfma4(ring[i][1], bv[1], acc1);
-          acc0 = mfma4(ring[i][2], bv[2], acc0);
-          acc1 = mfma4(ring[i][3], bv[3], acc1);
-        } else {
-          acc0 += bv * ring[i];
+      for (int i = 0; i < RING; ++i)
+        if (i < s.Qq) fr[i] = tp[i * 64];
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < RING; ++i)
+        if (i < s.Qq) {
+          const f4 bv = bq[i * 64];
+          acc0 = mfma4(fr[i][0], bv[0], acc0);
+          acc1 = mfma4(fr[i][1], bv[1], acc1);
+          acc0 = mfma4(fr[i][2], bv[2], acc0);
+          acc1 = mfma4(fr[i][3], bv[3], acc1);
         }
-        if (!ABL(dbg, 4)) ring[i] = np[(i < vn ? i : vn - 1) * 64 + lane];
-        bv = bn;
-      }
+      epi(s.mt0 + t, acc0 + acc1);
     }
-    {                                                     // last block; next block: next tile
-      const bool more = t + 1 < s.ntl;
-      gf4p np = more ? tp + (size_t)s.Qq * 64 : tp;
-      const int vn = more ? (s.Qq < RING ? s.Qq : RING) : 1;
-      lf4p bq = bp + (NB - 1) * RING * 64;
+    return;
+  }
+  // long rows: chunks of LCH quads through two register sets (2 x 16 registers: the kernels run at
+  // the 128-VGPR budget of 16-wave workgroups) -- the loads of chunk n + 1 are
+  // issued before the MFMAs of chunk n, unconditionally and in program order (a tile's last
+  // chunk reads up to LCH - 1 quads past the tile: the next tile's, the next table's or the
+  // padding behind the last table; never used), so the compiler's vmcnt counting stays exact
+  lf4p bp = (lf4p)(in + (g << 6) + (c << 2));
+  const int NCH = (s.Qq + LCH - 1) / LCH;
+  auto loadc = [&](f4 (&x)[LCH], gf4p tp, int ch) {
+    gf4p p = tp + (size_t)ch * LCH * 64;
 #pragma unroll
-      for (int i = 0; i < RING; ++i) {
-        if (i < vlast) {
-          f4 bn = bv;
-          if (i + 1 < vlast) bn = bq[(i + 1) * 64];
-          if (!ABL(dbg, 2)) {
-            acc0 = mfma4(ring[i][0], bv[0], acc0);
-            acc1 = mfma4(ring[i][1], bv[1], acc1);
-            acc0 = mfma4(ring[i][2], bv[2], acc0);
-            acc1 = mfma4(ring[i][3], bv[3], acc1);
-          } else {
-            acc0 += bv * ring[i];
-          }
-          bv = bn;
+    for (int i = 0; i < LCH; ++i) x[i] = p[i * 64];
+  };
+  for (int t = 0; t < s.ntl; ++t) {
+    gf4p tp = s.base + (size_t)t * s.Qq * 64 + lane;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const f4 (&x)[LCH], int ch) {
+      lf4p bq = bp + ch * LCH * 64;
+      const int v = s.Qq - ch * LCH;
+      if (v >= LCH) {
+#pragma unroll
+        for (int i = 0; i < LCH; ++i) {
+          const f4 bv = bq[i * 64];
+          acc0 = mfma4(x[i][0], bv[0], acc0);
+          acc1 = mfma4(x[i][1], bv[1], acc1);
+          acc0 = mfma4(x[i][2], bv[2], acc0);
+          acc1 = mfma4(x[i][3], bv[3], acc1);
         }
-        if (!ABL(dbg, 4)) ring[i] = np[(i < vn ? i : vn - 1) * 64 + lane];    // (no next tile: one quad again)
+      } else {
+#pragma unroll
+        for (int i = 0; i < LCH; ++i)
+          if (i < v) {
+            const f4 bv = bq[i * 64];
+            acc0 = mfma4(x[i][0], bv[0], acc0);
+            acc1 = mfma4(x[i][1], bv[1], acc1);
+            acc0 = mfma4(x[i][2], bv[2], acc0);
+            acc1 = mfma4(x[i][3], bv[3], acc1);
+          }
       }
+    };
+    f4 xa[LCH], xb[LCH];
+    loadc(xa, tp, 0);
+    for (int ch = 0;; ch += 2) {
+      loadc(xb, tp, ch + 1 < NCH ? ch + 1 : ch);         // (no next chunk: this one again, unused)
+      compute(xa, ch);
+      if (ch + 1 >= NCH) break;
+      loadc(xa, tp, ch + 2 < NCH ? ch + 2 : ch + 1);
+      compute(xb, ch + 1);
+      if (ch + 2 >= NCH) break;
     }
     epi(s.mt0 + t, acc0 + acc1);
   }
@@ -307,7 +316,7 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
   for (int l = 0; l < N.nl; ++l) {
     const GLayer L = N.l[l];
     const bool hidden = l + 1 < N.nl;
-    const FragStream cur = frag_stream(a.frag + L.f_off, L.Qp >> 2, L.MT);
+    const FragStream cur = frag_stream(a.frag + L.f_off, L.Qp >> 2, L.MT, L.per);
     if (hidden && tid < 16) other[pix(L.n_out * 16 + tid)] = 1.0f;      // bias unit of the next layer
     if (rec && !ABL(a.dbg, 8)) img_store(rec + (size_t)L.a_row * 16, in, L.n_in);
     GSTAMP(4, ts);
@@ -384,7 +393,7 @@ NJ_DEV lfp net_backward(const GArgs& a, const GNet& N, lfp din, lfp other, float
     for (int e = L.n_out * 16 + tid; e < L.QTp * 64; e += nth) din[pix(e)] = 0.0f;
     const float* acts = rec + (size_t)L.a_row * 16;        // this layer's input = act of layer l-1
     if (l > 0) acts_place(other, ar, acts, L.n_in * 16);
-    const FragStream cur = frag_stream(a.frag + L.ft_off, L.QTp >> 2, L.MTT);
+    const FragStream cur = frag_stream(a.frag + L.ft_off, L.QTp >> 2, L.MTT, L.pert);
     if (l - 1 >= l_lo && l - 1 > 0) {
       const GLayer& Ln = N.l[l - 1];
       acts_fetch(ar, rec + (size_t)Ln.a_row * 16, Ln.n_in * 16);

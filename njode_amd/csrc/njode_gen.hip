@@ -154,7 +154,7 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
     return false;
   }
   m.P = p_off;
-  m.frag_floats = f_off;
+  m.frag_floats = f_off + RING * 256;   // (+ one chunk: the product loop reads whole chunks)
   m.pack.total = f_off;
   // the vectors the kernels stage in the images besides layer inputs: ODE input, readouts, states
   if (a.IN0 + 4 > img_rows) img_rows = a.IN0 + 4;
@@ -430,6 +430,17 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
       return v;
     }();
     if (!getenv("NJODE_GEN_NW") && c.m.nw > 4 && (long long)c.L.NT >= 16LL * n_cu) c.m.nw = 4;
+  }
+  {
+    // output tiles per wave, now that the waves per workgroup are known
+    GNet* nets[3] = {&a.ode, &a.enc, &a.dec};
+    for (GNet* N : nets)
+      for (int l = 0; l < N->nl; ++l) {
+        N->l[l].per = cdiv(N->l[l].MT, c.m.nw);
+        N->l[l].pert = cdiv(N->l[l].MTT, c.m.nw);
+      }
+  }
+  if (c.L.seg) {
     GSeg& g = c.g;
     g.order = (const int*)(pw + c.L.order);
     g.item_prev = (const int*)(pw + c.L.item_prev);
