@@ -139,13 +139,13 @@ NJ_DEV float tanh_acc(float x) {   // few-ulp tanh (njode_device.h, NJ_ACC_TANH 
 NJ_DEV float act_rt(int act, float z) { return act == ACT_TANH ? tanh_acc(z) : fmaxf(z, 0.0f); }
 NJ_DEV float dact_rt(int act, float av) { return act == ACT_TANH ? 1.0f - av * av : (av > 0.0f ? 1.0f : 0.0f); }
 
-// dropout: one hash per (call seed, global path, time key, network) and chain, one fmix per unit
+// dropout: one hash per (call seed, global path, time key, network) and chain, one fmix per two units
 NJ_DEV uint32_t drop_base(const DropCtx& dc, unsigned long long gid, uint32_t tkey, uint32_t net) {
   return drop_state(dc, (uint32_t)gid, (uint32_t)(gid >> 32), tkey, net);
 }
-NJ_DEV bool drop_keep(uint32_t base, int layer, int unit, uint32_t thr16) {
-  const uint32_t h = fmix32(base ^ ((uint32_t)layer * 0x9e3779b9u + (uint32_t)unit * 0x85ebca6bu + 0x632be5abu));
-  return (h >> 16) >= thr16;
+// one word per PAIR of units: two 16-bit keep decisions (unit 2p: low half, unit 2p + 1: high half)
+NJ_DEV uint32_t drop_word(uint32_t base, int layer, int pair) {
+  return fmix32(base ^ ((uint32_t)layer * 0x9e3779b9u + (uint32_t)pair * 0x85ebca6bu + 0x632be5abu));
 }
 
 // ---- LDS images ------------------------------------------------------------------------------
@@ -335,7 +335,11 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
         }
         if (drop) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = drop_keep(dbase, l, u0 + r, a.dc.thr16) ? v[r] * a.dc.inv_keep : -0.0f;
+          for (int r = 0; r < 4; r += 2) {          // (u0 is a multiple of 4)
+            const uint32_t w = drop_word(dbase, l, (u0 + r) >> 1);
+            v[r] = (w & 0xffffu) >= a.dc.thr16 ? v[r] * a.dc.inv_keep : -0.0f;
+            v[r + 1] = (w >> 16) >= a.dc.thr16 ? v[r + 1] * a.dc.inv_keep : -0.0f;
+          }
         }
       }
 #pragma unroll
