@@ -1,4 +1,6 @@
-"""Ablation timing of the generic segment-plan kernels (diagnostic build -DNJ_GEN_ABL,
+"""(Bits 2, 4 and 32 acted on the fragment-ring version of the product loop measured in
+profiles/r03_generic_ablation.jsonl; the current loop has no ring and ignores them.)
+Ablation timing of the generic segment-plan kernels (diagnostic build -DNJ_GEN_ABL,
 tools/ubench/build_stamps.sh): the same training step with parts of the ODE forward switched off
 through NJODE_GEN_DBG bits (results are wrong by construction; only the kernel times are read).
   1 no activation / dropout in the epilogue   2 no MFMA (one vector op instead)
