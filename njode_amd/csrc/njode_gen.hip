@@ -324,11 +324,14 @@ int build_plan(const Layout& L, char* pw, const NjodeBatch* b, const NjodeSchedu
   k_gen_jlo<<<cdiv(K + 2, 256), 256, 0, st>>>(k_jump, nt, K, (int*)(pw + L.jlo));
   if (L.seg) {
     // items = rows linked along their path, sorted by length; tails sorted by length
+    k_gseg_init<<<cdiv(n, 256), 256, 0, st>>>(n, K, (int*)(pw + L.iota), (int*)(pw + L.t_of_row),
+                                              (int*)(pw + L.item_prev), (int*)(pw + L.item_next),
+                                              (int*)(pw + L.item_kbeg), (int*)(pw + L.item_len),
+                                              (unsigned*)(pw + L.key));
     k_gseg_link<<<cdiv(B, 64), 64, 0, st>>>(
         B, nt, K, dense, k_jump, (int*)(pw + L.t_of_row), (int*)(pw + L.item_prev), (int*)(pw + L.item_next),
         (int*)(pw + L.item_kbeg), (int*)(pw + L.item_len), (unsigned*)(pw + L.key), (int*)(pw + L.first_row),
         (int*)(pw + L.last_row), (unsigned*)(pw + L.tail_key), (int*)(pw + L.iota_b));
-    k_gseg_iota<<<cdiv(n, 256), 256, 0, st>>>(n, (int*)(pw + L.iota));
     size_t bytes = L.sort_tmp_bytes;
     HIP_TRY(sort_pairs(pw + L.sort_tmp, bytes, (const unsigned*)(pw + L.key), (unsigned*)(pw + L.key_sorted),
                        (const int*)(pw + L.iota), (int*)(pw + L.order), n, bits_for((unsigned)K), st));

@@ -64,6 +64,10 @@ NJ_DEV void store_rows(float* __restrict__ dst, lfp img, const int* ids, int W) 
   }
 }
 
+// (obs_idx is the caller's: a value outside [0, B) -- forbidden by the batch layout, reported under
+// NJODE_VALIDATE -- must not become an address)
+NJ_DEV int seg_path(const GArgs& a, int p) { return p < 0 ? 0 : (p >= a.B ? a.B - 1 : p); }
+
 NJ_DEV void seg_clear_lds(const GArgs& a, lfp smem) {
   const int n = gen_lds_floats(a.img_rows, a.D, a.H, a.DO);
   for (int e = threadIdx.x; e < n; e += blockDim.x) smem[e] = 0.0f;
@@ -86,7 +90,7 @@ __global__ void __launch_bounds__(1024) k_gseg_enc(GArgs a, GSeg g) {
     const int i = i0 + tid;
     const bool ok = i < n;
     ids[tid] = ok ? i : -1;
-    pathI[tid] = ok ? (start ? i : g.obs_idx[i]) : 0;
+    pathI[tid] = ok ? (start ? i : seg_path(a, g.obs_idx[i])) : 0;
     keyI[tid] = (ok && !start) ? g.k_jump[g.t_of_row[i]] : 0;
   }
   __syncthreads();
@@ -130,7 +134,7 @@ NJ_DEV void seg_tile_setup(const GArgs& a, const GSeg& g, GLds& S, SegTile& t, i
       if (i < a.n_obs) {
         row = g.order[i];
         prev = g.item_prev[row];
-        path = g.obs_idx[row];
+        path = seg_path(a, g.obs_idx[row]);
         kbeg = g.item_kbeg[row];
         len = g.item_len[row];
       }
@@ -270,7 +274,7 @@ __global__ void __launch_bounds__(1024) k_gseg_mid(GArgs a, GSeg g) {
   if (tid < 16) {
     const int r = tile * 16 + tid;
     const bool ok = r < a.n_obs;
-    const int path = ok ? g.obs_idx[r] : 0;
+    const int path = ok ? seg_path(a, g.obs_idx[r]) : 0;
     ids[tid] = ok ? r : -1;
     pathI[tid] = path;
     keyI[tid] = ok ? g.k_jump[g.t_of_row[r]] : 0;
@@ -462,9 +466,22 @@ __global__ void k_gseg_link(int B, int n_times, int K, const int* __restrict__ d
   tail_key[b] = (unsigned)kt;              // tail length K - kprev, descending
   iota_b[b] = b;
 }
-__global__ void k_gseg_iota(int n, int* __restrict__ iota) {
+// row numbers for the sort, and a harmless item (no steps, no neighbours) for every row: a row the
+// column walk does not reach -- a path listed twice in one time slice, which the batch layout
+// forbids -- then costs its observation, not memory safety
+__global__ void k_gseg_init(int n, int K, int* __restrict__ iota, int* __restrict__ t_of_row,
+                            int* __restrict__ item_prev, int* __restrict__ item_next,
+                            int* __restrict__ item_kbeg, int* __restrict__ item_len,
+                            unsigned* __restrict__ key) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) iota[i] = i;
+  if (i >= n) return;
+  iota[i] = i;
+  t_of_row[i] = 0;
+  item_prev[i] = -1;
+  item_next[i] = -1;
+  item_kbeg[i] = 0;
+  item_len[i] = 0;
+  key[i] = (unsigned)K;
 }
 // first ODE record of every item tile: exclusive scan of the tiles' lengths (one workgroup)
 __global__ void __launch_bounds__(1024) k_gseg_tiles(const int* __restrict__ order,

@@ -280,3 +280,26 @@ def test_segment_plan_agrees_with_the_lockstep_plan(name, monkeypatch):
     np.testing.assert_allclose(h_s, h_l, atol=2e-6, rtol=1e-5)
     assert rel_l2(g_s, g_l) < 2e-6, rel_l2(g_s, g_l)
     assert np.abs(g_s).max() > 0
+
+
+def test_segment_plan_survives_a_malformed_batch():
+    """A path listed twice in one time slice breaks the batch layout's contract (a path has at most
+    one row per slice; `NJODE_VALIDATE=1` reports it).  The segment plan then loses one of the two
+    observations -- it must not read or write out of bounds: the call completes with finite results."""
+    cfg = _cfg(1, 10, _w(100), _w(100), _w(100))
+    torch.manual_seed(2)
+    m = hip_model(cfg).train()
+    b, meta = bs_batch(40, seed=3)
+    tp = np.asarray(b['time_ptr'])
+    sizes = np.diff(tp)
+    i = int(np.argmax(sizes >= 2))                      # a slice with at least two rows
+    obs = b['obs_idx'].clone()
+    obs[tp[i] + 1] = obs[tp[i]]                         # the same path twice
+    bad = dict(b, obs_idx=obs)
+    _, loss = m.loss_and_grad(*_args(bad, meta['dt'], meta['maturity']))
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    assert torch.isfinite(m.flat_grad()).all()
+    # and the model is still usable
+    _, loss2 = m.loss_and_grad(*_args(b, meta['dt'], meta['maturity']))
+    assert np.isfinite(float(loss2)) and float(loss2) > 0
