@@ -204,9 +204,10 @@ NJ_DEV FragStream frag_stream(const float* __restrict__ ft, int Qq, int MT, int 
   s.base = (gf4p)(ft + (size_t)s.mt0 * Qq * 256);
   return s;
 }
-// all tiles of this wave.  epi(tile, acc) once per tile.
-template <class EPI>
-NJ_DEV void layer_product(const FragStream s, lfp in, EPI epi, int dbg = 0) {
+// all tiles of this wave.  pre(tile) right behind a tile's first fragment loads (loads of its own
+// that the epilogue needs ride along), epi(tile, acc) once per tile.
+template <class PRE, class EPI>
+NJ_DEV void layer_product(const FragStream s, lfp in, PRE pre, EPI epi, int dbg = 0) {
   if (s.ntl <= 0) return;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   if (s.Qq <= RING) {
@@ -219,6 +220,7 @@ NJ_DEV void layer_product(const FragStream s, lfp in, EPI epi, int dbg = 0) {
 #pragma unroll
       for (int i = 0; i < RING; ++i)
         if (i < s.Qq) fr[i] = tp[i * 64];
+      pre(s.mt0 + t);
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < RING; ++i)
@@ -274,6 +276,7 @@ NJ_DEV void layer_product(const FragStream s, lfp in, EPI epi, int dbg = 0) {
     };
     f4 xa[LCH], xb[LCH];
     loadc(xa, tp, 0);
+    pre(s.mt0 + t);
     for (int ch = 0;; ch += 2) {
       loadc(xb, tp, ch + 1 < NCH ? ch + 1 : ch);         // (no next chunk: this one again, unused)
       compute(xa, ch);
@@ -320,7 +323,7 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
     if (hidden && tid < 16) other[pix(L.n_out * 16 + tid)] = 1.0f;      // bias unit of the next layer
     if (rec && !ABL(a.dbg, 8)) img_store(rec + (size_t)L.a_row * 16, in, L.n_in);
     GSTAMP(4, ts);
-    layer_product(cur, in, [&](int mt, const f32x4& acc) {
+    layer_product(cur, in, [](int) {}, [&](int mt, const f32x4& acc) {
       lfp op = other + (mt << 8) + (c << 2) + g;
       const int u0 = 16 * mt + 4 * g;
       float v[4] = {acc[0], acc[1], acc[2], acc[3]};
@@ -359,59 +362,41 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
 // complete before the caller's barrier.  Stores the delta of every layer output to the record
 // (for the weight gradients) and leaves the gradient w.r.t. the network INPUT vector in the
 // returned image (n_in rows), unless !need_input (then the first layer's transposed product is
-// skipped).  The stored activations a layer's epilogue needs (act' and the keep bits) are fetched
-// one layer ahead into registers and placed in the OUTPUT image before the product, whose
-// epilogue then reads and overwrites its own element.
-constexpr int ACT_REGS = 8;
-NJ_DEV void acts_fetch(float (&ar)[ACT_REGS], const float* __restrict__ acts, int n) {
-  const int tid = threadIdx.x, nth = blockDim.x;
-#pragma unroll
-  for (int i = 0; i < ACT_REGS; ++i) {
-    const int e = tid + i * nth;
-    ar[i] = acts[e < n ? e : n - 1];
-  }
-}
-NJ_DEV void acts_place(lfp img, const float (&ar)[ACT_REGS], const float* __restrict__ acts, int n) {
-  const int tid = threadIdx.x, nth = blockDim.x;
-#pragma unroll
-  for (int i = 0; i < ACT_REGS; ++i) {
-    const int e = tid + i * nth;
-    if (e < n) img[pix(e)] = ar[i];
-  }
-  for (int e = tid + ACT_REGS * nth; e < n; e += nth) img[pix(e)] = acts[e];   // (widths > 8 nth / 16)
-}
+// skipped).  The stored activations a layer's epilogue needs (act' and the keep bits) are loaded by
+// the lane that uses them, right behind its tile's fragment loads.  One barrier per layer.
 NJ_DEV lfp net_backward(const GArgs& a, const GNet& N, lfp din, lfp other, float* rec, bool drop,
                         bool need_input) {
   const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int l_lo = need_input ? 0 : 1;                    // lowest layer whose transposed product runs
-  float ar[ACT_REGS];
-  if (N.nl - 1 >= l_lo && N.nl - 1 > 0) {
-    const GLayer& Lt = N.l[N.nl - 1];
-    acts_fetch(ar, rec + (size_t)Lt.a_row * 16, Lt.n_in * 16);
-  }
   for (int l = N.nl - 1; l >= 0; --l) {
     const GLayer L = N.l[l];
     img_store(rec + (size_t)L.d_row * 16, din, L.n_out);
     if (l < l_lo) break;
-    // rows up to the padded k range must be finite: they meet zero fragments
-    for (int e = L.n_out * 16 + tid; e < L.QTp * 64; e += nth) din[pix(e)] = 0.0f;
-    const float* acts = rec + (size_t)L.a_row * 16;        // this layer's input = act of layer l-1
-    if (l > 0) acts_place(other, ar, acts, L.n_in * 16);
-    const FragStream cur = frag_stream(a.frag + L.ft_off, L.QTp >> 2, L.MTT, L.pert);
-    if (l - 1 >= l_lo && l - 1 > 0) {
-      const GLayer& Ln = N.l[l - 1];
-      acts_fetch(ar, rec + (size_t)Ln.a_row * 16, Ln.n_in * 16);
+    // rows up to the padded k range must be finite (they meet zero fragments): the caller's image
+    // here, the image this layer produces below
+    if (l == N.nl - 1) {
+      for (int e = L.n_out * 16 + tid; e < L.QTp * 64; e += nth) din[pix(e)] = 0.0f;
+      __syncthreads();
     }
-    __syncthreads();
+    if (l - 1 >= l_lo)
+      for (int e = L.n_in * 16 + tid; e < N.l[l - 1].QTp * 64; e += nth) other[pix(e)] = 0.0f;
+    const float* acts = rec + (size_t)L.a_row * 16;        // this layer's input = act of layer l-1
+    const FragStream cur = frag_stream(a.frag + L.ft_off, L.QTp >> 2, L.MTT, L.pert);
     const int pact = l > 0 ? N.l[l - 1].act : -1;
-    layer_product(cur, din, [&](int mt, const f32x4& acc) {
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    layer_product(cur, din, [&](int mt) {
+      if (l > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * mt + 4 * g + r;
+          av[r] = acts[(u < L.n_in ? u : 0) * 16 + c];
+        }
+      }
+    }, [&](int mt, const f32x4& acc) {
       lfp op = other + (mt << 8) + (c << 2) + g;
       const int u0 = 16 * mt + 4 * g;
       float v[4] = {acc[0], acc[1], acc[2], acc[3]};
       if (l > 0) {
-        float av[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = op[r << 6];
         if (drop) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
