@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r3d
-timeout 1500 python tools/bench_configs.py > gpurun_out/r3d/configs_sweep.jsonl 2> gpurun_out/r3d/configs_sweep.err
-cut -c1-260 gpurun_out/r3d/configs_sweep.jsonl
-tail -2 gpurun_out/r3d/configs_sweep.err
+python bench.py > gpurun_out/r3d/bench_final3.json 2> gpurun_out/r3d/bench_final3.err
+head -c 400 gpurun_out/r3d/bench_final3.json
