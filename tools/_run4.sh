@@ -1,4 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r3d
-python bench.py > gpurun_out/r3d/bench_final3.json 2> gpurun_out/r3d/bench_final3.err
-head -c 400 gpurun_out/r3d/bench_final3.json
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1
+echo "rc=$?"
+tail -6 gpurun_out/smoke.log
