@@ -267,10 +267,17 @@ Layout make_layout(const Model& m, int B, int n_obs, int nt, int K, int call_fla
     L.slab = L.take((size_t)m.S * m.P * 4);
     // (segment plan: sum over the item tiles of their longest item <= K + B K / 16 records)
     L.rec_ode = L.take(((size_t)(K > 0 ? K : 1) * (T + 1) + 1) * m.a.ode.rec_rows * 64);
-    L.rec_enc = L.take(((size_t)nt * T + T) * m.a.enc.rec_rows * 64);
-    L.rec_dec = L.take(ntl * T * 2 * m.a.dec.rec_rows * 64);
-    L.ybuf = L.take(ntl * T * 2 * m.a.DO * 64);
-    L.flags = L.take(ntl * T * 4);
+    if (L.seg) {
+      // one encoder record per row tile and path tile, two readout records per row tile
+      L.rec_enc = L.take(((size_t)L.NT + T) * m.a.enc.rec_rows * 64);
+      L.rec_dec = L.take((size_t)L.NT * 2 * m.a.dec.rec_rows * 64);
+      L.ybuf = L.flags = 0;
+    } else {
+      L.rec_enc = L.take(((size_t)nt * T + T) * m.a.enc.rec_rows * 64);
+      L.rec_dec = L.take(ntl * T * 2 * m.a.dec.rec_rows * 64);
+      L.ybuf = L.take(ntl * T * 2 * m.a.DO * 64);
+      L.flags = L.take(ntl * T * 4);
+    }
   } else {
     L.slab = L.rec_ode = L.rec_enc = L.rec_dec = L.ybuf = L.flags = 0;
   }

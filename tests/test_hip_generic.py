@@ -303,3 +303,38 @@ def test_segment_plan_survives_a_malformed_batch():
     # and the model is still usable
     _, loss2 = m.loss_and_grad(*_args(b, meta['dt'], meta['maturity']))
     assert np.isfinite(float(loss2)) and float(loss2) > 0
+
+
+@pytest.mark.timeout(900)
+def test_generic_segment_plan_at_config4_shard_size():
+    """125 000 paths (BASELINE config 4's per-rank shard) of the width-100 model on the generic
+    segment plan: ~1.2 M work items, ~0.8 M ODE records, a 35 GB workspace.  Size-independent
+    property: two data-parallel shards add up to the whole batch (loss and gradient), dropout on."""
+    sys.path.insert(0, REPO)
+    import bench
+    N = 125000
+    cfg = _cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1)
+    torch.manual_seed(0)
+    m = hip_model(cfg).train()
+    dev = torch.device('cuda', 0)
+
+    def args_of(lo, hi):
+        b, meta = bench.make_global_slice(lo, hi)
+        return (b['times'], b['time_ptr'], b['X'].to(dev), b['obs_idx'].to(dev, torch.int32), meta['dt'],
+                meta['maturity'], b['start_X'].to(dev), b['n_obs_ot'].to(dev, torch.int32))
+
+    m._step_counter = 1
+    m.dp_global_batch, m.dp_path_offset = N, 0
+    _, loss = m.loss_and_grad(*args_of(0, N))
+    g_full = m.flat_grad().clone()
+    assert np.isfinite(float(loss)) and float(loss) > 0
+    total, g_sum = 0.0, torch.zeros_like(g_full)
+    for lo, hi in ((0, 60000), (60000, N)):
+        m._step_counter = 1
+        m.dp_global_batch, m.dp_path_offset = N, lo
+        _, l = m.loss_and_grad(*args_of(lo, hi))
+        total += float(l)
+        g_sum += m.flat_grad()
+    m.dp_global_batch, m.dp_path_offset = None, 0
+    assert total == pytest.approx(float(loss), rel=1e-5)
+    assert float((g_sum - g_full).norm() / g_full.norm()) < 1e-4
