@@ -21,9 +21,15 @@ def _step(m, args, kw, prefetch, left=0):
     return float(loss), m.flat_grad().clone()
 
 
+WIDE = ((100, 'tanh'), (100, 'tanh'))      # the shape-generic kernels (a plan of their own: items sorted by rocPRIM)
+
+
+@pytest.mark.parametrize('nets', [None, WIDE], ids=['demo', 'generic_w100'])
 @pytest.mark.parametrize('n_paths', [300, 3000])
-def test_prefetched_plan_gives_identical_results_on_the_segment_plan(n_paths):
+def test_prefetched_plan_gives_identical_results_on_the_segment_plan(n_paths, nets):
     cfg = demo_cfg(dropout=0.1, device_outputs=True)
+    if nets is not None:
+        cfg.update(ode_nn=nets, enc_nn=nets, readout_nn=nets)
     torch.manual_seed(0)
     m = models.NJODE(**cfg).cuda().train()
     b, meta = bs_batch(n_paths, seed=4)
