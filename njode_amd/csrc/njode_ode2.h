@@ -125,6 +125,14 @@ NJ_DEV void act_load(const float* act, long long b16, int tile, int lane, float 
 #pragma unroll
   for (int q = 0; q < Q1; ++q) a2[q] = p[(Q1 + q) * 64];
 }
+// one layer's half of a record (LAYER 0: a1, 1: a2)
+template <class C, int LAYER>
+NJ_DEV void act_load_half(const float* act, long long b16, int tile, int lane, float (&x)[MF<C>::Q1]) {
+  constexpr int Q1 = MF<C>::Q1;
+  const float* p = act_block<C>((float*)act, b16, tile) + lane + LAYER * Q1 * 64;
+#pragma unroll
+  for (int q = 0; q < Q1; ++q) x[q] = p[q * 64];
+}
 // act'(z) from a stored activation; 0 for a dropped unit (stored as -0.0f)
 template <int ACT, bool DROP> NJ_DEV float dact_stored(float av) {
   const float d = dact_f<ACT>(av);
@@ -423,6 +431,41 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       dtt = act ? a.step_dt[kk] : 0.0f;
       tt = a.step_t[kk];
     };
+#ifndef NJ_BWD_DIRECT
+#define NJ_BWD_DIRECT 1      // (0: the round-2 form with a second register set, for A/B builds)
+#endif
+#if NJ_BWD_DIRECT
+    // the next step's checkpoint and activations are loaded INTO the registers of the current
+    // ones as soon as those are dead (h after the input vector, a2 after delta2, a1 after delta1):
+    // no second register set, no copies, waits spread over the step; loads are unconditional
+    // (step 0 reloads itself) so that the compiler counts them
+    float h[M::QH], a1[M::Q1], a2[M::Q1], dt_n = 0.0f, t_n = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::QH; ++q) h[q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < M::Q1; ++q) { a1[q] = 0.0f; a2[q] = 0.0f; }
+    if (nmax > 0) fetch(nmax - 1, h, a1, a2, dt_n, t_n);
+    for (int s = nmax - 1; s >= 0; --s) {
+      const float dt = dt_n, t = t_n;
+      const int sp = s > 0 ? s - 1 : 0;
+      const long long b16p = a.base16_s[sp];
+      float b0[M::Q0];
+      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      {
+        const bool act = sp < it.n;
+        const int kk = act ? it.kbeg + sp : 0;
+        const float* rec = a.traj + (act ? (size_t)(a.base_s[sp] + j) * C::H : 0);
+#pragma unroll
+        for (int q = 0; q < M::QH; ++q) {
+          const int u = 4 * q + g;
+          const float v = rec[u < C::H ? u : 0];
+          h[q] = u < C::H ? v : 0.0f;
+        }
+        dt_n = act ? a.step_dt[kk] : 0.0f;
+        t_n = a.step_t[kk];
+      }
+      F.begin();
+#else
     float h_n[M::QH], a1_n[M::Q1], a2_n[M::Q1], dt_n = 0.0f, t_n = 0.0f;
 #pragma unroll
     for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
@@ -440,6 +483,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       float b0[M::Q0];
       in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
       F.begin();
+#endif
 
       // ---- layer 3: h' = h + dt f  =>  delta3 = dt * lam (zero for inactive chains)
       float d3[M::QH];
@@ -467,6 +511,9 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
       for (int q = 0; q < M::QW; ++q)
         d2[q] = acc[q / 4][q % 4] * (BWD_ABL(32) ? 1.0f : dact_stored<C::ACT, DROP>(a2[q]));
+#if NJ_BWD_DIRECT
+      act_load_half<C, 1>(a.act, b16p, tile, lane, a2);
+#endif
       if (!BWD_ABL(4)) wave_lds_sync();
 
       // ---- layer 2
@@ -491,6 +538,9 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
       for (int q = 0; q < M::QW; ++q)
         d1[q] = acc[q / 4][q % 4] * (BWD_ABL(32) ? 1.0f : dact_stored<C::ACT, DROP>(a1[q]));
+#if NJ_BWD_DIRECT
+      act_load_half<C, 0>(a.act, b16p, tile, lane, a1);
+#endif
       if (!BWD_ABL(4)) wave_lds_sync();
 
       // ---- layer 1

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../.."
 OBJ=njode_amd/csrc/_obj
 for bits in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DNJ_BWD_ABL=$bits \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DNJ_BWD_ABL=$bits ${NJ_BWD_EXTRA} \
     -DNJ_ID=0 -DNJ_PART=1 -DNJ_D=1 -DNJ_H=10 -DNJ_DO=1 -DNJ_NH=2 -DNJ_W=50 -DNJ_ACT=0 -DNJ_MASKED=0 \
     -DNJ_CURT=0 -DNJ_RES=1 -DNJ_ACC_TANH=0 -DNJ_RNN=0 njode_amd/csrc/njode_cfg.hip -o tools/ubench/cfg0_1_abl$bits.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ubench/libnjode_bwdabl_$bits.so \
