@@ -52,7 +52,7 @@ using FS = FragSize<(HAS_MFMA || HAS_MFMA_LOCK), C>;
 constexpr int MF_FLOATS = FS::ode + FS::enc + FS::dec + FS::ode;   // + the scaled ODE table (frag2)
 constexpr int FRAG2_OFF = FS::ode + FS::enc + FS::dec;
 template <bool ON, class CC> struct ActSize { static constexpr int value = 0; };
-template <class CC> struct ActSize<true, CC> { static constexpr int value = 8 * MF<CC>::Q1; };
+template <class CC> struct ActSize<true, CC> { static constexpr int value = StepRec<CC>::PER_CHAIN; };
 constexpr int ACT_FLOATS = ActSize<HAS_SPLIT, C>::value;   // stored activations: demo-family shapes
 
 // All fragment tables of the three networks in ONE launch instead of three in

@@ -147,36 +147,67 @@ template <int NQ> NJ_DEV void split_get(lfp X, float (&v)[NQ], int g, int c) {
   for (int q = 0; q < NQ; ++q) v[q] = X[(4 * q + g) * IMG_STRIDE + c];
 }
 
-// wave w's share of a tile's stored-activation block (njode_ode2.h): registers 4w .. 4w+3
-// (no branch around the stores -- registers beyond Q1 go to `trash` -- so that the compiler
-// can count them, see ode2_fwd_single)
+// wave w's share of a tile's step record (StepRec, njode_ode2.h): its registers 4w .. 4w+3 of
+// a1 / a2 are quad w of group B / A; the wave that holds the layers' leftover registers (wave
+// NF; wave 3 when there are none) also stores group A's tail list -- those leftovers and the
+// state h, of which every wave keeps a copy -- and a1's leftovers.  No branch around the stores:
+// what a wave does not own goes to the `trash` block, so that the compiler can count them
+// (see ode2_fwd_single).
 template <class C>
-NJ_DEV void split_act_store(float* act, long long b16, int tile, int lane, int w, const float (&a1u)[4],
-                            const float (&a2u)[4], float* trash) {
-  constexpr int Q1 = MF<C>::Q1;
-  float* p = act_block<C>(act, b16, tile) + lane;
+NJ_DEV void split_rec_store(float* blk, float* trash, int lane, int w, const float (&a1u)[4],
+                            const float (&a2u)[4], const float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
+  float* bq = w < R::NF ? blk : trash;
+  quad_store(bq + w * 256 + lane * 4, a2u[0], a2u[1], a2u[2], a2u[3]);
+  quad_store(bq + R::GA + w * 256 + lane * 4, a1u[0], a1u[1], a1u[2], a1u[3]);
+  float a2x[MF<C>::Q1];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const bool ok = 4 * w + r < Q1;
-    float* d1 = ok ? p + (4 * w + r) * 64 : trash;
-    float* d2 = ok ? p + (Q1 + 4 * w + r) * 64 : trash;
-    *d1 = a1u[r];
-    *d2 = a2u[r];
+  for (int q = 0; q < MF<C>::Q1; ++q) a2x[q] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < R::L1; ++i) a2x[4 * R::NF + i] = a2u[i];
+  rec_tail_store<C>(w == R::WT ? blk : trash, lane, a2x, h);
+  if constexpr (R::L1 > 0) {
+    float* bs = w == R::NF ? blk : trash;
+#pragma unroll
+    for (int i = 0; i < R::L1; ++i) bs[R::B1S + i * 64 + lane] = a1u[i];
   }
 }
-template <class C>
-NJ_DEV void split_act_load(const float* act, long long b16, int tile, int lane, int w, float (&a1u)[4],
-                           float (&a2u)[4]) {
-  constexpr int Q1 = MF<C>::Q1;
-  const float* p = act_block<C>((float*)act, b16, tile) + lane;
+// the loaded words of a step record, RAW: they cross the loop's back edge as they are and are
+// sorted into (a1u, a2u, h) where the step starts (a select next to a load would put the
+// load's s_waitcnt there)
+template <class C> struct SplitRecRaw {
+  using R = StepRec<C>;
+  f32x4 qa, qb;
+  float a2x[MF<C>::Q1], h[MF<C>::QH], s1[R::L1 > 0 ? R::L1 : 1];
+  NJ_DEV void zero() {
+    qa = qb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int q = 4 * w + r < Q1 ? 4 * w + r : 0;
-    const float x1 = p[q * 64], x2 = p[(Q1 + q) * 64];
-    a1u[r] = 4 * w + r < Q1 ? x1 : 0.0f;
-    a2u[r] = 4 * w + r < Q1 ? x2 : 0.0f;
+    for (int q = 0; q < MF<C>::Q1; ++q) a2x[q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < MF<C>::QH; ++q) h[q] = 0.0f;
+    s1[0] = 0.0f;
   }
-}
+  NJ_DEV void load(const float* blk, int lane, int w) {
+    const int wq = w < R::NF ? w : 0;
+    qa = *(const f32x4*)(blk + wq * 256 + lane * 4);
+    qb = *(const f32x4*)(blk + R::GA + wq * 256 + lane * 4);
+    rec_tail_load<C>(blk, lane, a2x, h);
+#pragma unroll
+    for (int i = 0; i < R::L1; ++i) s1[i] = blk[R::B1S + i * 64 + lane];
+  }
+  NJ_DEV void unpack(int w, float (&a1u)[4], float (&a2u)[4], float (&hh)[MF<C>::QH]) const {
+    const bool own = w < R::NF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float l2 = r < R::L1 ? a2x[4 * R::NF + (r < R::L1 ? r : 0)] : 0.0f;
+      const float l1 = r < R::L1 ? s1[r < R::L1 ? r : 0] : 0.0f;
+      a2u[r] = own ? qa[r] : l2;
+      a1u[r] = own ? qb[r] : l1;
+    }
+#pragma unroll
+    for (int q = 0; q < MF<C>::QH; ++q) hh[q] = h[q];
+  }
+};
 
 // forward of the two hidden layers for the own tile; leaves a1 (all units) gathered
 template <class C, bool DROP, bool BWD>
@@ -235,9 +266,10 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
   for (int i = threadIdx.x; i < XFLOATS; i += 256) lds_raw[i] = 0.0f;
   SplitFrags<C, false> F;
   F.load(a.frag, w, lane);
+  In0Const<C> K0;
+  K0.init(g);
   __syncthreads();
 
-  constexpr bool ACTS = SAVE;   // compile time: see ode2_fwd_single
   const int n_items = TAIL ? a.B : a.n_obs;
   const int n_tiles = tile1 - tile0;
   float* const trash = a.trash + lane * C::H;
@@ -256,44 +288,34 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
       const int u = 4 * q + g;
       h[q] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
     }
-    const int nmax = wave_max(it.n);
-    float dt_n = 0.0f, t_n = 0.0f;
-    long long base_n = 0, b16_n = 0;
+    const int nmax = uniform(wave_max(it.n));   // (scalar step loop: see ode2_fwd_single)
+    float dt_r = 0.0f, t_r = 0.0f;
+    long long b16_n = 0;
     if (nmax > 0) {
       const int k0 = it.n > 0 ? it.kbeg : 0;
-      dt_n = it.n > 0 ? a.step_dt[k0] : 0.0f;
-      t_n = a.step_t[k0];
-      base_n = SAVE ? a.base_s[0] : 0;
-      b16_n = ACTS ? a.base16_s[0] : 0;
+      dt_r = a.step_dt[k0];
+      t_r = a.step_t[k0];
+      b16_n = SAVE ? sload_ll(a.base16_s, 0) : 0;
     }
+    vm_drain();
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
-      const float dt = dt_n, t = t_n;
-      const long long base = base_n, b16 = b16_n;
-      if (s + 1 < nmax) {
-        const bool act_n = s + 1 < it.n;
-        const int kn = act_n ? it.kbeg + s + 1 : 0;
-        dt_n = act_n ? a.step_dt[kn] : 0.0f;
-        t_n = a.step_t[kn];
-        if constexpr (SAVE) base_n = a.base_s[s + 1];
-        if constexpr (ACTS) b16_n = a.base16_s[s + 1];
-      }
-      if constexpr (SAVE) {
-        float* rec = (active && w == 0) ? a.traj + (size_t)(base + j) * C::H : trash;
-#pragma unroll
-        for (int q = 0; q < M::QH; ++q) {
-          const int u = 4 * q + g;
-          float* dst = u < C::H ? rec + u : trash;
-          *dst = h[q];
-        }
+      const float dt = active ? dt_r : 0.0f, t = t_r;
+      const long long b16 = b16_n;
+      {
+        const int sn = s + 1 < nmax ? s + 1 : s;
+        const int kn = sn < it.n ? it.kbeg + sn : 0;
+        dt_r = a.step_dt[kn];
+        t_r = a.step_t[kn];
+        if constexpr (SAVE) b16_n = sload_ll(a.base16_s, sn);
       }
       float b0[M::Q0], a1l[4], a2l[4], a1u[4], a2u[4];
-      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      in0_fill_c<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g, K0);
       uint32_t k1, k2;
       split_keep_bits<C, DROP>(a, it.b, k, g, w, k1, k2);
       split_hidden_layers<C, DROP, false>(F, X1, b0, a1l, a2l, a1u, a2u, k1, k2, a.dc.inv_keep, g, c, w);
-      if constexpr (ACTS) split_act_store<C>(a.act, b16, tile, lane, w, a1u, a2u, trash);
+      if constexpr (SAVE) split_rec_store<C>(rec_block<C>(a.act, b16, tile), a.trash, lane, w, a1u, a2u, h);
       f32x4 part = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -522,6 +544,8 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
   for (int i = threadIdx.x; i < 2 * XFLOATS + 4 * M::QH * 64 + 4 * 4 * TFLOATS; i += 256) lds_raw[i] = 0.0f;
   SplitFragsT<C> F;
   F.load(a.frag, w, lane);
+  In0Const<C> K0;
+  K0.init(g);
   __syncthreads();
 
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -543,35 +567,26 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
       const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
       lam[q] = (valid && u < C::H) ? v : 0.0f;
     }
-    const int nmax = wave_max(it.n);
-    auto fetch = [&](int s, float (&hh)[M::QH], float (&x1)[4], float (&x2)[4], float& dtt, float& tt) {
-      const bool act = s < it.n;
-      const int kk = act ? it.kbeg + s : 0;
-      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j) * C::H : 0);
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) {
-        const int u = 4 * q + g;
-        const float v = rec[u < C::H ? u : 0];
-        hh[q] = u < C::H ? v : 0.0f;
-      }
-      split_act_load<C>(a.act, a.base16_s[s], tile, lane, w, x1, x2);
-      dtt = act ? a.step_dt[kk] : 0.0f;
-      tt = a.step_t[kk];
+    const int nmax = uniform(wave_max(it.n));   // (scalar step loop, scalar record address)
+    // the record and the schedule values of step s - 1 are loaded while step s runs, RAW
+    SplitRecRaw<C> nx;
+    nx.zero();
+    float dt_r = 0.0f, t_r = 0.0f;
+    auto fetch = [&](int s) {
+      const int kk = s < it.n ? it.kbeg + s : 0;
+      nx.load(rec_block<C>(a.act, sload_ll(a.base16_s, s), tile), lane, w);
+      dt_r = a.step_dt[kk];
+      t_r = a.step_t[kk];
     };
-    float h_n[M::QH], a1_n[4] = {0.f, 0.f, 0.f, 0.f}, a2_n[4] = {0.f, 0.f, 0.f, 0.f}, dt_n = 0.0f, t_n = 0.0f;
-#pragma unroll
-    for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
-    if (nmax > 0) fetch(nmax - 1, h_n, a1_n, a2_n, dt_n, t_n);
+    if (nmax > 0) fetch(nmax - 1);
+    vm_drain();
     for (int s = nmax - 1; s >= 0; --s) {
       float h[M::QH], a1u[4], a2u[4];
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) h[q] = h_n[q];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { a1u[r] = a1_n[r]; a2u[r] = a2_n[r]; }
-      const float dt = dt_n, t = t_n;
-      if (s > 0) fetch(s - 1, h_n, a1_n, a2_n, dt_n, t_n);
+      nx.unpack(w, a1u, a2u, h);
+      const float dt = s < it.n ? dt_r : 0.0f, t = t_r;
+      fetch(s > 0 ? s - 1 : 0);
       float b0[M::Q0], a1l[4], a2l[4];
-      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      in0_fill_c<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g, K0);
       // the forward's activations are loaded, not recomputed: with the factor 1 / (1 - p) they
       // are the images' operands; all-gather a1 for the dW2 product
       const float ik = DROP ? a.dc.inv_keep : 1.0f;
@@ -699,7 +714,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
     if (save) ode_fwd_split<C, DROP, false, true>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
     else ode_fwd_split<C, DROP, false, false>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
   } else {
-    const int wave = ((int)blockIdx.x - ns) * 4 + (threadIdx.x >> 6);
+    const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
     // one-wave role on the scaled fragments (njode_ode2.h): same masks, same values to rounding
     const int nw = ((int)gridDim.x - ns) * 4;
     if (save) ode2_fwd_single<C, DROP, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
@@ -721,7 +736,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   if ((int)blockIdx.x < ns) {
     ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
   } else {
-    const int wave = ((int)blockIdx.x - ns) * 4 + (threadIdx.x >> 6);
+    const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
     ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
   }
 }

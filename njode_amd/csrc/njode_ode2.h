@@ -94,45 +94,189 @@ template <int ACT> NJ_DEV float act2_f(float zs) {
 }
 
 
-// ---- stored activations ----------------------------------------------------------------
+// in0 with the lane's CONSTANT entries (bias unit 1, padding 0) in a register computed once per
+// kernel: left as literals in the per-step select chain, `g == 1 ? 1.0f : 0.0f` comes back from
+// the compiler as two nested exec-mask branches in the middle of the Euler-step loop, which
+// splits the loop body into three blocks and makes every s_waitcnt at their joins conservative
+template <class C, int U> constexpr bool in0_var() {
+  return U < C::H + C::D + 2 + (C::CURT ? 1 : 0);
+}
+template <class C> struct In0Const {
+  float v[MF<C>::Q0];
+  NJ_DEV void init(int g) {
+    const float z[C::D] = {};
+#pragma unroll
+    for (int q = 0; q < MF<C>::Q0; ++q) v[q] = 0.0f;
+    init_q<0>(g, z);
+  }
+  template <int Q> NJ_DEV void init_q(int g, const float (&z)[C::D]) {
+    if constexpr (Q < MF<C>::Q0) {
+      const float e0 = in0_var<C, 4 * Q + 0>() ? 0.0f : in0_unit<C, 4 * Q + 0>(0.0f, z, 0.0f, 0.0f);
+      const float e1 = in0_var<C, 4 * Q + 1>() ? 0.0f : in0_unit<C, 4 * Q + 1>(0.0f, z, 0.0f, 0.0f);
+      const float e2 = in0_var<C, 4 * Q + 2>() ? 0.0f : in0_unit<C, 4 * Q + 2>(0.0f, z, 0.0f, 0.0f);
+      const float e3 = in0_var<C, 4 * Q + 3>() ? 0.0f : in0_unit<C, 4 * Q + 3>(0.0f, z, 0.0f, 0.0f);
+      float x = g == 0 ? e0 : (g == 1 ? e1 : (g == 2 ? e2 : e3));
+      asm volatile("" : "+v"(x));
+      v[Q] = x;
+      init_q<Q + 1>(g, z);
+    }
+  }
+};
+template <class C, int Q>
+NJ_DEV void in0_fill_c(float (&b0)[MF<C>::Q0], const float (&h)[MF<C>::QH], const float (&tx)[C::D],
+                       float tau, float tdiff, int g, const In0Const<C>& K) {
+  if constexpr (Q < MF<C>::Q0) {
+    float th = 0.0f;
+    if constexpr (4 * Q < C::H) th = tanh_f(h[Q]);
+    float x = K.v[Q];
+    if constexpr (in0_var<C, 4 * Q + 3>()) x = g == 3 ? in0_unit<C, 4 * Q + 3>(th, tx, tau, tdiff) : x;
+    if constexpr (in0_var<C, 4 * Q + 2>()) x = g == 2 ? in0_unit<C, 4 * Q + 2>(th, tx, tau, tdiff) : x;
+    if constexpr (in0_var<C, 4 * Q + 1>()) x = g == 1 ? in0_unit<C, 4 * Q + 1>(th, tx, tau, tdiff) : x;
+    if constexpr (in0_var<C, 4 * Q + 0>()) x = g == 0 ? in0_unit<C, 4 * Q + 0>(th, tx, tau, tdiff) : x;
+    b0[Q] = x;
+    in0_fill_c<C, Q + 1>(b0, h, tx, tau, tdiff, g, K);
+  }
+}
+
+// ---- stored step records ----------------------------------------------------------------
 // While the f32 pipe (matrix + vector: one pipe on gfx950) bounds the ODE kernels, HBM idles:
-// the forward stores the two hidden activation vectors of every Euler step (WITHOUT the
-// inverted-dropout factor; a dropped unit as -0.0f) and the backward reads them instead of
-// recomputing 68 of its 241 MFMAs, 58 transcendentals and the dropout stream.  Layout: the
-// block of tile t at Euler step s starts at chain record base16_s[s] + 16 t (KArgs), a record
-// is 8 Q1 floats; inside the block register q of layer l of lane `lane` sits at
-// (l Q1 + q) 64 + lane: every wave-level store / load is one contiguous 256-byte line.
-template <class C> NJ_DEV float* act_block(float* act, long long b16, int tile) {
-  return act + (size_t)(b16 + 16 * (long long)tile) * (8 * MF<C>::Q1);
+// the forward stores, for every Euler step of a tile of 16 chains, the state before the step and
+// the two hidden activation vectors (WITHOUT the inverted-dropout factor; a dropped unit as
+// -0.0f), and the backward reads them instead of recomputing 68 of its 241 MFMAs, 58
+// transcendentals and the dropout stream.
+//
+// Layout (round 4: LANE-MAJOR quads).  The record of tile t at Euler step s starts at chain
+// record base16_s[s] + 16 t (KArgs) and holds, per lane, the 2 Q1 + QH registers
+//   group A = a2[0 .. Q1), h[0 .. QH)     group B = a1[0 .. Q1)
+// in the order the backward needs them.  Four consecutive registers of a lane are one 16-byte
+// quad and the 64 lanes' quads are contiguous, so a wave moves a quad with ONE
+// global_load/store_dwordx4 (1 KB, fully coalesced); what does not fill a quad is stored as
+// single dwords [register][lane].  Per layer the first NF = Q1 / 4 quads are whole (in the
+// four-wave role they are exactly the registers wave 0 .. NF-1 own); group A's tail list
+// (a2's L1 = Q1 % 4 leftover registers, then h) follows as quads + singles; group B ends with
+// a1's L1 leftovers as singles.  W = 50, H = 10: A = 3 + 1 quads, B = 3 quads + 1 dword --
+// 8 memory instructions per lane and step where the register-major layout of round 2/3 took
+// 26 dwords + 3 dwords of a separate 40-byte checkpoint record (whose address hung on a
+// per-step load of its own).  Size: (2 Q1 + QH) 4 floats per chain record (464 B).
+template <class C> struct StepRec {
+  using M = MF<C>;
+  static constexpr int Q1 = M::Q1, QH = M::QH;
+  static constexpr int NF = Q1 / 4, L1 = Q1 % 4;
+  static constexpr int NT = L1 + QH, NTQ = NT / 4, NTS = NT % 4;   // group A's tail list
+  static constexpr int TAILQ = NF * 256;                            // float offsets in the block
+  static constexpr int TAILS = (NF + NTQ) * 256;
+  static constexpr int GA = TAILS + NTS * 64;
+  static constexpr int B1S = GA + NF * 256;
+  static constexpr int FLOATS = B1S + L1 * 64;
+  static constexpr int PER_CHAIN = FLOATS / 16;
+  static constexpr int WT = NF < 3 ? NF : 3;   // four-wave role: the wave that stores the tail list
+  static_assert(FLOATS == (2 * Q1 + QH) * 64, "step record: every register exactly once");
+};
+template <class C> NJ_DEV float* rec_block(const float* act, long long b16, int tile) {
+  return (float*)act + (size_t)(b16 + 16 * (long long)tile) * StepRec<C>::PER_CHAIN;
+}
+NJ_DEV void quad_store(float* p, float x, float y, float z, float w) {
+  const f32x4 v = {x, y, z, w};
+  *(f32x4*)p = v;
+}
+// tail list of group A from a2's leftovers and h (compile-time index)
+template <class C, int I>
+NJ_DEV float rec_tail_get(const float (&a2)[MF<C>::Q1], const float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
+  if constexpr (I < R::L1) return a2[4 * R::NF + I];
+  else if constexpr (I < R::NT) return h[I - R::L1];
+  else return 0.0f;
+}
+template <class C, int I>
+NJ_DEV void rec_tail_put(float v, float (&a2)[MF<C>::Q1], float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
+  if constexpr (I < R::L1) a2[4 * R::NF + I] = v;
+  else if constexpr (I < R::NT) h[I - R::L1] = v;
+}
+template <class C, int K = 0>
+NJ_DEV void rec_tail_store(float* blk, int lane, const float (&a2)[MF<C>::Q1], const float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
+  if constexpr (K < R::NTQ) {
+    quad_store(blk + R::TAILQ + K * 256 + lane * 4, rec_tail_get<C, 4 * K>(a2, h),
+               rec_tail_get<C, 4 * K + 1>(a2, h), rec_tail_get<C, 4 * K + 2>(a2, h),
+               rec_tail_get<C, 4 * K + 3>(a2, h));
+    rec_tail_store<C, K + 1>(blk, lane, a2, h);
+  } else if constexpr (K < R::NTQ + R::NTS) {
+    blk[R::TAILS + (K - R::NTQ) * 64 + lane] = rec_tail_get<C, 4 * R::NTQ + (K - R::NTQ)>(a2, h);
+    rec_tail_store<C, K + 1>(blk, lane, a2, h);
+  }
+}
+template <class C, int K = 0>
+NJ_DEV void rec_tail_load(const float* blk, int lane, float (&a2)[MF<C>::Q1], float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
+  if constexpr (K < R::NTQ) {
+    const f32x4 v = *(const f32x4*)(blk + R::TAILQ + K * 256 + lane * 4);
+    rec_tail_put<C, 4 * K>(v[0], a2, h);
+    rec_tail_put<C, 4 * K + 1>(v[1], a2, h);
+    rec_tail_put<C, 4 * K + 2>(v[2], a2, h);
+    rec_tail_put<C, 4 * K + 3>(v[3], a2, h);
+    rec_tail_load<C, K + 1>(blk, lane, a2, h);
+  } else if constexpr (K < R::NTQ + R::NTS) {
+    rec_tail_put<C, 4 * R::NTQ + (K - R::NTQ)>(blk[R::TAILS + (K - R::NTQ) * 64 + lane], a2, h);
+    rec_tail_load<C, K + 1>(blk, lane, a2, h);
+  }
+}
+// one wave holds the whole tile (bulk role): group A = a2 + h, group B = a1
+template <class C>
+NJ_DEV void rec_store_A(float* blk, int lane, const float (&a2)[MF<C>::Q1], const float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
+#pragma unroll
+  for (int k = 0; k < R::NF; ++k)
+    quad_store(blk + k * 256 + lane * 4, a2[4 * k], a2[4 * k + 1], a2[4 * k + 2], a2[4 * k + 3]);
+  rec_tail_store<C>(blk, lane, a2, h);
 }
 template <class C>
-NJ_DEV void act_store(float* act, long long b16, int tile, int lane, const float (&a1)[MF<C>::Q1],
-                      const float (&a2)[MF<C>::Q1]) {
-  constexpr int Q1 = MF<C>::Q1;
-  float* p = act_block<C>(act, b16, tile) + lane;
+NJ_DEV void rec_store_B(float* blk, int lane, const float (&a1)[MF<C>::Q1]) {
+  using R = StepRec<C>;
 #pragma unroll
-  for (int q = 0; q < Q1; ++q) p[q * 64] = a1[q];
+  for (int k = 0; k < R::NF; ++k)
+    quad_store(blk + R::GA + k * 256 + lane * 4, a1[4 * k], a1[4 * k + 1], a1[4 * k + 2], a1[4 * k + 3]);
 #pragma unroll
-  for (int q = 0; q < Q1; ++q) p[(Q1 + q) * 64] = a2[q];
+  for (int i = 0; i < R::L1; ++i) blk[R::B1S + i * 64 + lane] = a1[4 * R::NF + i];
 }
 template <class C>
-NJ_DEV void act_load(const float* act, long long b16, int tile, int lane, float (&a1)[MF<C>::Q1],
-                     float (&a2)[MF<C>::Q1]) {
-  constexpr int Q1 = MF<C>::Q1;
-  const float* p = act_block<C>((float*)act, b16, tile) + lane;
+NJ_DEV void rec_load_A(const float* blk, int lane, float (&a2)[MF<C>::Q1], float (&h)[MF<C>::QH]) {
+  using R = StepRec<C>;
 #pragma unroll
-  for (int q = 0; q < Q1; ++q) a1[q] = p[q * 64];
-#pragma unroll
-  for (int q = 0; q < Q1; ++q) a2[q] = p[(Q1 + q) * 64];
+  for (int k = 0; k < R::NF; ++k) {
+    const f32x4 v = *(const f32x4*)(blk + k * 256 + lane * 4);
+    a2[4 * k] = v[0]; a2[4 * k + 1] = v[1]; a2[4 * k + 2] = v[2]; a2[4 * k + 3] = v[3];
+  }
+  rec_tail_load<C>(blk, lane, a2, h);
 }
-// one layer's half of a record (LAYER 0: a1, 1: a2)
-template <class C, int LAYER>
-NJ_DEV void act_load_half(const float* act, long long b16, int tile, int lane, float (&x)[MF<C>::Q1]) {
-  constexpr int Q1 = MF<C>::Q1;
-  const float* p = act_block<C>((float*)act, b16, tile) + lane + LAYER * Q1 * 64;
+template <class C>
+NJ_DEV void rec_load_B(const float* blk, int lane, float (&a1)[MF<C>::Q1]) {
+  using R = StepRec<C>;
 #pragma unroll
-  for (int q = 0; q < Q1; ++q) x[q] = p[q * 64];
+  for (int k = 0; k < R::NF; ++k) {
+    const f32x4 v = *(const f32x4*)(blk + R::GA + k * 256 + lane * 4);
+    a1[4 * k] = v[0]; a1[4 * k + 1] = v[1]; a1[4 * k + 2] = v[2]; a1[4 * k + 3] = v[3];
+  }
+#pragma unroll
+  for (int i = 0; i < R::L1; ++i) a1[4 * R::NF + i] = blk[R::B1S + i * 64 + lane];
 }
+// a wave-uniform value the compiler cannot see is uniform (reduced through lane permutes, or
+// derived from threadIdx): in an SGPR, so that loops on it are scalar loops and loads indexed
+// by it are scalar loads
+NJ_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// base16_s[i] through the scalar cache (s_load): the table is written by the plan kernels of an
+// earlier launch; through a plain pointer the compiler, seeing the kernel's own stores, would
+// fetch it with a vector load + s_waitcnt vmcnt(0) + v_readfirstlane
+// Everything in flight lands before a step loop starts (its first step needs the prologue's
+// loads at once anyway).  The point is the compiler's bookkeeping: at a loop header it merges
+// the counter states of the entry and of the back edge, and a prologue whose loads are issued in
+// another order than the steady state's turns a counted wait (vmcnt(8): "all but the eight
+// stores of this step") into vmcnt(0) for every step of the loop.  (A builtin, not inline asm:
+// the waitcnt pass has to see it.)
+NJ_DEV void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), others untouched
+typedef const long long __attribute__((address_space(4))) * cllp;
+NJ_DEV long long sload_ll(const long long* p, int i) { return ((cllp)(unsigned long long)p)[i]; }
+
 // act'(z) from a stored activation; 0 for a dropped unit (stored as -0.0f)
 template <int ACT, bool DROP> NJ_DEV float dact_stored(float av) {
   const float d = dact_f<ACT>(av);
@@ -248,8 +392,9 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
   const int g = lane >> 4, c = lane & 15;
   Ode2FwdFrags<C> F;
   F.load(a.frag2, lane);
+  In0Const<C> K0;
+  K0.init(g);
 
-  constexpr bool ACTS = SAVE;   // the saving forward of these kernels always has a.act
   const int n_items = TAIL ? a.B : a.n_obs;
   const int n_tiles = tile1 - tile0;
   float* const trash = a.trash + lane * C::H;
@@ -268,40 +413,33 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
       const int u = 4 * q + g;
       h[q] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
     }
-    const int nmax = wave_max(it.n);
-    float dt_n = 0.0f, t_n = 0.0f;
-    long long base_n = 0, b16_n = 0;
+    // (uniform: the step loop is a scalar loop, base16_s[s] a scalar load; the per-lane
+    // schedule values of the next step are loaded one step ahead and carried RAW across the
+    // back edge -- a select next to a load puts its s_waitcnt there)
+    const int nmax = uniform(wave_max(it.n));
+    float dt_r = 0.0f, t_r = 0.0f;
+    long long b16_n = 0;
     if (nmax > 0) {
       const int k0 = it.n > 0 ? it.kbeg : 0;
-      dt_n = it.n > 0 ? a.step_dt[k0] : 0.0f;
-      t_n = a.step_t[k0];
-      base_n = SAVE ? a.base_s[0] : 0;
-      b16_n = ACTS ? a.base16_s[0] : 0;
+      dt_r = a.step_dt[k0];
+      t_r = a.step_t[k0];
+      b16_n = SAVE ? sload_ll(a.base16_s, 0) : 0;
     }
+    vm_drain();
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
-      const float dt = dt_n, t = t_n;
-      const long long base = base_n, b16 = b16_n;
-      if (s + 1 < nmax) {
-        const bool act_n = s + 1 < it.n;
-        const int kn = act_n ? it.kbeg + s + 1 : 0;
-        dt_n = act_n ? a.step_dt[kn] : 0.0f;
-        t_n = a.step_t[kn];
-        if constexpr (SAVE) base_n = a.base_s[s + 1];
-        if constexpr (ACTS) b16_n = a.base16_s[s + 1];
-      }
-      if constexpr (SAVE) {
-        float* rec = active ? a.traj + (size_t)(base + j) * C::H : trash;
-#pragma unroll
-        for (int q = 0; q < M::QH; ++q) {
-          const int u = 4 * q + g;
-          float* dst = u < C::H ? rec + u : trash;
-          *dst = h[q];
-        }
+      const float dt = active ? dt_r : 0.0f, t = t_r;
+      const long long b16 = b16_n;
+      {
+        const int sn = s + 1 < nmax ? s + 1 : s;
+        const int kn = sn < it.n ? it.kbeg + sn : 0;
+        dt_r = a.step_dt[kn];
+        t_r = a.step_t[kn];
+        if constexpr (SAVE) b16_n = sload_ll(a.base16_s, sn);
       }
       float b0[M::Q0];
-      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
+      in0_fill_c<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g, K0);
       uint32_t st = 0;
       if constexpr (DROP) {
         const unsigned long long gid = a.gid0 + it.b;
@@ -310,8 +448,13 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
       }
       float a1[M::Q1], a2[M::Q1];
       hidden_layer2<C, DROP, M::Q0>(F.A1, b0, a1, st, a.dc.thr16, g);
+      float* blk = nullptr;
+      if constexpr (SAVE) {
+        blk = rec_block<C>(a.act, b16, tile);
+        rec_store_B<C>(blk, lane, a1);
+      }
       hidden_layer2<C, DROP, M::Q1>(F.A2, a1, a2, st, a.dc.thr16, g);
-      if constexpr (ACTS) act_store<C>(a.act, b16, tile, lane, a1, a2);
+      if constexpr (SAVE) rec_store_A<C>(blk, lane, a2, h);
       f32x4 f[M::MTH];
       out_layer2<C>(F.A3, a2, f);
 #pragma unroll
@@ -383,6 +526,8 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   __syncthreads();
   FR F;
   F.init(fimg, lane);
+  In0Const<C> K0;
+  K0.init(g);
 
   f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -414,76 +559,37 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
       lam[q] = (valid && u < C::H) ? v : 0.0f;
     }
-    const int nmax = BWD_ABL(64) ? 0 : wave_max(it.n);
-    // checkpoint, activations and scalars of a step are loaded while the previous one runs
-    auto fetch = [&](int s, float (&hh)[M::QH], float (&x1)[M::Q1], float (&x2)[M::Q1], float& dtt,
-                     float& tt) {
-      const bool act = s < it.n;
-      const int kk = act ? it.kbeg + s : 0;
-      const float* rec = a.traj + (act ? (size_t)(a.base_s[s] + j) * C::H : 0);
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) {
-        const int u = 4 * q + g;
-        const float v = rec[u < C::H ? u : 0];
-        hh[q] = u < C::H ? v : 0.0f;
-      }
-      act_load<C>(a.act, a.base16_s[s], tile, lane, x1, x2);
-      dtt = act ? a.step_dt[kk] : 0.0f;
-      tt = a.step_t[kk];
+    // (uniform: scalar step loop, base16_s[s] a scalar load)
+    const int nmax = BWD_ABL(64) ? 0 : uniform(wave_max(it.n));
+    // The record of the NEXT step (s - 1) is loaded INTO the registers of the current one as
+    // soon as those are dead (a2 and h after delta2, a1 after delta1: no second register set,
+    // no copies, waits spread over the step).  Loads are unconditional (step 0 reloads itself)
+    // and their values cross the back edge RAW, so that the compiler counts them and no wait
+    // sits next to a load; the record's address hangs on scalar loads only.
+    auto load_sched = [&](int s, float& dtr, float& tr) {
+      const int kk = s < it.n ? it.kbeg + s : 0;
+      dtr = a.step_dt[kk];
+      tr = a.step_t[kk];
     };
-#ifndef NJ_BWD_DIRECT
-#define NJ_BWD_DIRECT 1      // (0: the round-2 form with a second register set, for A/B builds)
-#endif
-#if NJ_BWD_DIRECT
-    // the next step's checkpoint and activations are loaded INTO the registers of the current
-    // ones as soon as those are dead (h after the input vector, a2 after delta2, a1 after delta1):
-    // no second register set, no copies, waits spread over the step; loads are unconditional
-    // (step 0 reloads itself) so that the compiler counts them
-    float h[M::QH], a1[M::Q1], a2[M::Q1], dt_n = 0.0f, t_n = 0.0f;
+    float h[M::QH], a1[M::Q1], a2[M::Q1], dt_r = 0.0f, t_r = 0.0f;
 #pragma unroll
     for (int q = 0; q < M::QH; ++q) h[q] = 0.0f;
 #pragma unroll
     for (int q = 0; q < M::Q1; ++q) { a1[q] = 0.0f; a2[q] = 0.0f; }
-    if (nmax > 0) fetch(nmax - 1, h, a1, a2, dt_n, t_n);
+    if (nmax > 0) {   // (in the order of the steady state: the waits at the loop head count on it)
+      const float* blk = rec_block<C>(a.act, sload_ll(a.base16_s, nmax - 1), tile);
+      load_sched(nmax - 1, dt_r, t_r);
+      rec_load_A<C>(blk, lane, a2, h);
+      rec_load_B<C>(blk, lane, a1);
+    }
     for (int s = nmax - 1; s >= 0; --s) {
-      const float dt = dt_n, t = t_n;
+      const float dt = s < it.n ? dt_r : 0.0f, t = t_r;
       const int sp = s > 0 ? s - 1 : 0;
-      const long long b16p = a.base16_s[sp];
+      const float* blkp = rec_block<C>(a.act, sload_ll(a.base16_s, sp), tile);
       float b0[M::Q0];
-      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
-      {
-        const bool act = sp < it.n;
-        const int kk = act ? it.kbeg + sp : 0;
-        const float* rec = a.traj + (act ? (size_t)(a.base_s[sp] + j) * C::H : 0);
-#pragma unroll
-        for (int q = 0; q < M::QH; ++q) {
-          const int u = 4 * q + g;
-          const float v = rec[u < C::H ? u : 0];
-          h[q] = u < C::H ? v : 0.0f;
-        }
-        dt_n = act ? a.step_dt[kk] : 0.0f;
-        t_n = a.step_t[kk];
-      }
+      in0_fill_c<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g, K0);
+      if (!BWD_ABL(8)) load_sched(sp, dt_r, t_r);
       F.begin();
-#else
-    float h_n[M::QH], a1_n[M::Q1], a2_n[M::Q1], dt_n = 0.0f, t_n = 0.0f;
-#pragma unroll
-    for (int q = 0; q < M::QH; ++q) h_n[q] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < M::Q1; ++q) { a1_n[q] = 0.0f; a2_n[q] = 0.0f; }
-    if (nmax > 0) fetch(nmax - 1, h_n, a1_n, a2_n, dt_n, t_n);
-    for (int s = nmax - 1; s >= 0; --s) {
-      float h[M::QH], a1[M::Q1], a2[M::Q1];
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) h[q] = h_n[q];
-#pragma unroll
-      for (int q = 0; q < M::Q1; ++q) { a1[q] = a1_n[q]; a2[q] = a2_n[q]; }
-      const float dt = dt_n, t = t_n;
-      if (s > 0 && !BWD_ABL(8)) fetch(s - 1, h_n, a1_n, a2_n, dt_n, t_n);
-      float b0[M::Q0];
-      in0_fill<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g);
-      F.begin();
-#endif
 
       // ---- layer 3: h' = h + dt f  =>  delta3 = dt * lam (zero for inactive chains)
       float d3[M::QH];
@@ -511,9 +617,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
       for (int q = 0; q < M::QW; ++q)
         d2[q] = acc[q / 4][q % 4] * (BWD_ABL(32) ? 1.0f : dact_stored<C::ACT, DROP>(a2[q]));
-#if NJ_BWD_DIRECT
-      act_load_half<C, 1>(a.act, b16p, tile, lane, a2);
-#endif
+      if (!BWD_ABL(8)) rec_load_A<C>(blkp, lane, a2, h);
       if (!BWD_ABL(4)) wave_lds_sync();
 
       // ---- layer 2
@@ -538,9 +642,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
       for (int q = 0; q < M::QW; ++q)
         d1[q] = acc[q / 4][q % 4] * (BWD_ABL(32) ? 1.0f : dact_stored<C::ACT, DROP>(a1[q]));
-#if NJ_BWD_DIRECT
-      act_load_half<C, 0>(a.act, b16p, tile, lane, a1);
-#endif
+      if (!BWD_ABL(8)) rec_load_B<C>(blkp, lane, a1);
       if (!BWD_ABL(4)) wave_lds_sync();
 
       // ---- layer 1
