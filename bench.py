@@ -160,14 +160,17 @@ def cpu_baseline(meta_dt, T):
             'cpu_model': _cpu_model_name(), 'host_cpu_count': os.cpu_count()}
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r03_final_pmc_summary.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r04_final_pmc_summary.json')
 
 
 def _lib_sha256():
+    """sha256 of the library the process actually LOADED (njode_amd._lib.LIB_PATH: $NJODE_LIB when
+    an ablation / stamp build is selected), so that counters of another build are never reported."""
     import hashlib
+    from njode_amd import _lib
     h = hashlib.sha256()
     try:
-        with open(os.path.join(ROOT, 'njode_amd', 'libnjode_hip.so'), 'rb') as f:
+        with open(_lib.LIB_PATH, 'rb') as f:
             for chunk in iter(lambda: f.read(1 << 20), b''):
                 h.update(chunk)
     except OSError:
@@ -271,21 +274,83 @@ def _free_port():
     return port
 
 
-def spawn_ranks(n, argv):
+def count_gpus_without_runtime():
+    """Number of AMD GPUs of this node WITHOUT touching the HIP / ROCr runtime (the parent of the
+    ranks must never initialise the GPU: a later exec / fork of an initialised process is what the
+    pool forbids, and `torch.cuda.device_count()` is `hipGetDeviceCount` on a ROCm torch without
+    amdsmi).  KFD's topology lists every node; GPUs are the nodes with `simd_count > 0`.  The
+    visibility variables the runtime would apply are applied here too.  Returns None when the
+    topology is not readable (no KFD: not a ROCm box)."""
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        nodes = sorted(os.listdir(root), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0')) > 0:
+            n += 1
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = [x for x in v.split(',') if x.strip() != '']
+            n = min(n, len(listed))
+    return n
+
+
+def spawn_ranks(n, argv, rank_timeout=900.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
-    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relay their
-    output (rank 0 prints the JSON line) and return their exit code.  This parent never touches
-    the GPU and never replaces itself."""
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) in a process
+    group of their own, relay rank 0's JSON line and return their exit code.  This parent never
+    touches the GPU (devices are counted from KFD's topology, not through the runtime) and never
+    replaces itself.  `rank_timeout` seconds without the children finishing (a hung rendezvous,
+    a rank that died before the first collective) kills the whole group and returns 124; when
+    the ranks fail, the tail of their stderr (torchrun names the first failing rank) is shown."""
     share = os.environ.get('NJODE_BENCH_SHARE_GPU') == '1'
-    n_dev = torch.cuda.device_count()            # (does not initialise the GPU)
-    if n_dev < n and not share:
+    n_dev = count_gpus_without_runtime()
+    if n_dev is not None and n_dev < n and not share:
         print('bench.py: --gpus {} but this node has {} GPU(s)'.format(n, n_dev), file=sys.stderr)
         return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.abspath(__file__)] + list(argv)
-    return subprocess.call(cmd, env=env)
+    import signal
+    import tempfile
+    with tempfile.TemporaryFile(mode='w+') as err:
+        child = subprocess.Popen(cmd, env=env, stderr=err, start_new_session=True)
+        try:
+            rc = child.wait(timeout=rank_timeout if rank_timeout and rank_timeout > 0 else None)
+        except subprocess.TimeoutExpired:
+            rc = 124
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(child.pid, sig)      # the launcher AND its ranks (own session)
+                except ProcessLookupError:
+                    break
+                try:
+                    child.wait(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            print('bench.py: the {} ranks did not finish within {:.0f} s (--rank-timeout): process '
+                  'group killed'.format(n, rank_timeout), file=sys.stderr)
+        err.seek(0)
+        text = err.read()
+    if rc != 0:
+        tail = text.strip().splitlines()[-40:]
+        print('bench.py: ranks exited with code {}; last lines of their stderr:'.format(rc),
+              file=sys.stderr)
+        for line in tail:
+            print('  | ' + line, file=sys.stderr)
+    elif text:
+        sys.stderr.write(text)
+    return rc
 
 
 def main():
@@ -306,13 +371,16 @@ def main():
                     help='rank 0 saves the flat parameter vector after the timed steps (.npy)')
     ap.add_argument('--no-plan-prefetch', action='store_true',
                     help='build every step\'s plan in line instead of one step ahead')
+    ap.add_argument('--rank-timeout', type=float, default=900.0,
+                    help='self-spawned ranks (--gpus N without a launcher): kill the ranks\' process '
+                         'group and exit 124 after this many seconds (0: wait for ever)')
     args = ap.parse_args()
 
     launched = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
     if args.gpus > 1 and not launched:
         # no launcher: spawn the ranks.  Nothing in this process has touched the GPU
-        # (importing torch and counting devices does not initialise it).
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        # (importing torch does not initialise it; devices are counted from KFD's topology).
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -422,11 +490,12 @@ def main():
     elapsed = float(t)
     # the ranks' losses are partial sums over their shards (global denominator): add them up;
     # and every rank must hold the same parameters after the same all-reduced steps
+    # (N > 1: the loss was all-reduced WITH the gradient -- the last slot of the bucket -- by the
+    # last optimizer step: `loss` is a view of that slot and holds the global loss already)
     lsum = loss.detach().reshape(1).to(torch.float64).clone()
     flat = flat_after
     identical = True
     if distributed:
-        torch.distributed.all_reduce(lsum)
         pmax, pmin = flat.clone(), flat.clone()
         torch.distributed.all_reduce(pmax, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(pmin, op=torch.distributed.ReduceOp.MIN)
@@ -462,7 +531,7 @@ def main():
             out['rccl_world'] = torch.distributed.get_world_size()
             out['collective_backend'] = backend + (' (RCCL)' if backend == 'nccl' else '')
             out['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 5)
-            out['allreduce_floats'] = int(model.flat_grad().numel())
+            out['allreduce_floats'] = int(model.grad_bucket().numel())   # gradient + the loss slot
             out['ms_per_step_by_rank'] = [round(1e3 * x / args.steps, 4) for x in per_rank]
         if kern:
             per = {k: round(v[1] / max(v[0], 1), 5) for k, v in kern.items()}

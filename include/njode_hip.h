@@ -98,6 +98,11 @@ typedef struct NjodeDims {
                                    built ahead of time by njode_plan_f32 (below)              */
 #define NJODE_C_NEED_HT 0x100    /* (njode_plan_f32) the forward will be asked for hT         */
 #define NJODE_C_SCHED_TAIL 0x40  /* (with SCHED_KNOWN) k_jump[n_times-1] < n_steps             */
+#define NJODE_C_GEN_LOCKSTEP 0x200 /* shape-generic kernels: keep an unmasked loss call on the lockstep
+                                   plan (A/B runs, tests).  A CALL flag -- the same value must be
+                                   given to njode_plan_f32, the forward and its backward, which lay
+                                   the plan and the workspace out by it -- not an environment
+                                   variable the library would re-read in each of the three       */
 
 /*
  * Time grid of one forward pass: the float64 clock of NJODE.forward

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -209,8 +210,10 @@ hipError_t sort_pairs(void* tmp, size_t& bytes, const unsigned* k_in, unsigned* 
 // the path: training and loss-only evaluation.  NJODE_GEN_PLAN=lock keeps them on the lockstep
 // plan (A/B measurements; tests compare the two plans).
 bool use_seg(const Model& m, int n_obs, int call_flags) {
-  const char* env = getenv("NJODE_GEN_PLAN");     // (read per call: tests switch it)
-  const bool lock_only = env && strcmp(env, "lock") == 0;
+  // (the choice travels in the call flags, NJODE_C_GEN_LOCKSTEP: plan, forward and backward of one
+  // step lay their buffers out by it and must agree -- the Python class reads NJODE_GEN_PLAN once
+  // per step and sets the flag)
+  const bool lock_only = (call_flags & NJODE_C_GEN_LOCKSTEP) != 0;
   return !lock_only && !m.a.masked && n_obs > 0 && (call_flags & NJODE_C_GET_LOSS) &&
          !(call_flags & NJODE_C_RETURN_PATH);
 }
@@ -295,6 +298,14 @@ int check_sizes(const NjodeBatch* b, const NjodeSchedule* s) {
     return fail(NJODE_E_BADARG, "null schedule array");
   if ((size_t)s->n_times * (size_t)b->batch_size > ((size_t)1 << 31))
     return fail(NJODE_E_UNSUPPORTED, "n_times x batch_size exceeds 2^31 cells");
+  // k_jump (host array): non-decreasing and within [0, n_steps].  The segment plan sizes its
+  // record buffers by it (a path's item lengths add up to at most n_steps only then), so a
+  // malformed schedule must stop here, not write past the workspace.
+  for (int i = 0, prev = 0; i < s->n_times; ++i) {
+    const int k = s->k_jump[i];
+    if (k < prev || k > s->n_steps) return fail(NJODE_E_BADARG, "k_jump is not non-decreasing within [0, n_steps]");
+    prev = k;
+  }
   return NJODE_OK;
 }
 
@@ -432,13 +443,23 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
     // fit on the chip at once, four waves per tile (each walks several output tiles) run four
     // tiles per CU and pay the per-wave, per-layer scalar work a quarter as often
     // (profiles/r03_generic_waves_per_tile.txt: width 100, 20 000 paths: 8.0 -> 5.8 ms).
-    static const int n_cu = [] {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-        v = 256;
-      return v;
-    }();
+    // (per device: a process may drive GPUs of different sizes)
+    static std::mutex cu_mu;
+    static int cu_of_dev[64] = {};
+    int n_cu = 256;
+    {
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        std::lock_guard<std::mutex> lk(cu_mu);
+        if (cu_of_dev[dev] <= 0) {
+          int v = 0;
+          if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+          cu_of_dev[dev] = v;
+        }
+        n_cu = cu_of_dev[dev];
+      }
+    }
     if (!getenv("NJODE_GEN_NW") && c.m.nw > 4 && (long long)c.L.NT >= 16LL * n_cu) c.m.nw = 4;
   }
   {

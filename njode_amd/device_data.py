@@ -138,25 +138,15 @@ class DeviceDataset:
                 self.nb_obs.cpu().numpy().astype(np.int64))
 
     # -- batches -------------------------------------------------------------------------
-    def collate(self, idx=None, func_names=(), stream=None):
+    def collate(self, idx=None, func_names=()):
         """The batch ``custom_collate_fn`` builds for dataset rows ``idx`` (device int32
         tensor / array-like in batch order; None = the whole dataset), with ``X``,
         ``start_X``, ``obs_idx`` (int32) and ``n_obs_ot`` (int32) on the device and
         ``times`` / ``time_ptr`` as numpy arrays.
 
         The per-time counts must reach the host before ``X`` can be sized, so the call waits for
-        its own first kernel.  ``stream``: run the collate there (a side stream) -- the wait then
-        covers the collate only, not the training step queued on the current stream, and the
-        returned dict carries ``'ready'``, an event the consumer's stream must wait for."""
-        if stream is not None:
-            cur = torch.cuda.current_stream(self.device)
-            with torch.cuda.stream(stream):
-                out = self.collate(idx, func_names)
-                out['ready'] = torch.cuda.Event()
-                out['ready'].record(stream)
-            for k in ('X', 'start_X', 'obs_idx', 'n_obs_ot'):
-                out[k].record_stream(cur)
-            return out
+        its own first kernel (``prepare_batches`` + ``fill_batch`` is the form without a wait per
+        batch: one host round trip per epoch)."""
         L = _lib.lib()
         dev = self.device
         if idx is not None:

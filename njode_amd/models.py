@@ -302,6 +302,9 @@ class NJODE(torch.nn.Module):
         self._flat = None
         self._flat_checks = 0
         self._flat_grad = None
+        self._grad_bucket = None
+        self.dp_loss_in_bucket = False
+        self._flat_present = None
         self._param_slices = None
         self._flat_params = None
         self._ones = None
@@ -376,15 +379,25 @@ class NJODE(torch.nn.Module):
         total = sum(n for _, n, _ in slots)
         flat = torch.zeros(total, dtype=torch.float32, device=dev)
         slices, params, off = [], [], 0
+        present = None
         for p, n, shape in slots:
             if p is not None:
                 flat[off:off + n].copy_(p.data.reshape(-1).to(torch.float32))
                 p.data = flat[off:off + n].view(shape)
                 slices.append((off, n, shape))
                 params.append(p)
+            else:
+                # a slot without a parameter (bias=False, models.py:140-166): the kernels read it
+                # as zeros and WRITE its gradient; it is not a parameter, so the fused optimizer
+                # must leave it alone (FusedAdam.step multiplies the gradient by this mask)
+                if present is None:
+                    present = torch.ones(total, dtype=torch.float32, device=dev)
+                present[off:off + n] = 0.0
             off += n
         self._flat, self._param_slices, self._flat_params = flat, slices, params
+        self._flat_present = present
         self._flat_grad = None
+        self._grad_bucket = None
 
     def flat_parameters(self):
         """The flat parameter vector all Linear parameters are views of."""
@@ -393,13 +406,29 @@ class NJODE(torch.nn.Module):
 
     def flat_grad(self):
         """A flat gradient vector whose slices are installed as ``.grad`` of the
-        parameters (for the fused training step)."""
+        parameters (for the fused training step).  It is the head of ``grad_bucket()``."""
         self._ensure_flat()
         if self._flat_grad is None:
-            self._flat_grad = torch.zeros_like(self._flat)
+            # ONE bucket: the flat gradient and, behind it, one slot for the step's scalar loss,
+            # so that a data-parallel step all-reduces both with a single collective
+            # (SURVEY 8e: "one RCCL all-reduce (sum) of the flat fp32 gradient [P] + the scalar loss")
+            self._grad_bucket = torch.zeros(self._flat.numel() + 1, dtype=torch.float32,
+                                            device=self._flat.device)
+            self._flat_grad = self._grad_bucket[:-1]
             for (off, n, shape), p in zip(self._param_slices, self._flat_params):
                 p.grad = self._flat_grad[off:off + n].view(shape)
         return self._flat_grad
+
+    def grad_bucket(self):
+        """[P + 1] floats: ``flat_grad()`` followed by the loss slot (``loss_slot()``)."""
+        self.flat_grad()
+        return self._grad_bucket
+
+    def loss_slot(self):
+        """The last element of the bucket: where ``loss_and_grad`` writes the step's loss when
+        ``dp_loss_in_bucket`` is set (``FusedAdam(distributed=True)`` sets it).  It then holds this
+        rank's partial loss until ``FusedAdam.step()`` and the GLOBAL loss afterwards."""
+        return self.grad_bucket()[-1:]
 
     # -- library plumbing ---------------------------------------------------------------
     def _get_dims(self):
@@ -520,7 +549,11 @@ class NJODE(torch.nn.Module):
                  | (_lib.C_SAVE_BWD if save_bwd else 0)
                  # the plan decision travels with the call: the backward never re-reads the
                  # pinned schedule buffer, which the ring may have handed to a later forward
-                 | _lib.C_SCHED_KNOWN | (_lib.C_SCHED_TAIL if sched.has_tail() else 0))
+                 | _lib.C_SCHED_KNOWN | (_lib.C_SCHED_TAIL if sched.has_tail() else 0)
+                 # shape-generic kernels, A/B switch NJODE_GEN_PLAN=lock: read HERE, once per step,
+                 # and carried by the flags to the plan, the forward and the backward alike (a
+                 # plan prefetched under the other setting no longer matches and is dropped)
+                 | (_lib.C_GEN_LOCKSTEP if os.environ.get('NJODE_GEN_PLAN') == 'lock' else 0))
         if plan_only:   # prefetch_plan: the structs of the call, nothing allocated or counted
             return dims, cb, cs, flags, keep + [pinned], slot_i, (B, n_obs, nt, K)
         if plan is not None or (plan_key is not None and self._plans):
@@ -738,7 +771,10 @@ class NJODE(torch.nn.Module):
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
             M, save_bwd=True, plan_key=(obs_idx, time_ptr), want_hT=self.masked, plan=plan)
         dev = start_X.device
-        loss = torch.empty(1, dtype=torch.float32, device=dev)   # (always written: sum of the terms)
+        # (always written: sum of the terms; data parallel: written INTO the gradient bucket, see
+        # loss_slot())
+        loss = (self.loss_slot() if self.dp_loss_in_bucket
+                else torch.empty(1, dtype=torch.float32, device=dev))
         # hT is only skipped on the segment plan (unmasked): there it would cost an extra
         # per-path tail evolve; the lockstep plan produces it anyway
         hT = (torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
@@ -799,6 +835,8 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.distributed = distributed
+        # data parallel: the step's loss travels in the gradient's bucket (one collective)
+        model.dp_loss_in_bucket = bool(distributed)
         self.group = process_group
         self.time_allreduce = False
         self._allreduce_events = []
@@ -809,18 +847,23 @@ class FusedAdam:
     def step(self):
         m = self.model
         flat, grad = m.flat_parameters(), m.flat_grad()
+        if m._flat_present is not None:
+            # slots without a parameter (bias=False) take no update: zero gradient, zero moments,
+            # zero L2 term -> they stay exactly 0, as the C ABI requires (include/njode_hip.h)
+            grad.mul_(m._flat_present)
         if self.exp_avg.device != flat.device:
             self.exp_avg = self.exp_avg.to(flat.device)
             self.exp_avg_sq = self.exp_avg_sq.to(flat.device)
         if self.distributed:
+            bucket = m.grad_bucket()      # gradient [P] + the scalar loss: ONE all-reduce
             if self.time_allreduce:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-                torch.distributed.all_reduce(grad, group=self.group)
+                torch.distributed.all_reduce(bucket, group=self.group)
                 ev[1].record()
                 self._allreduce_events.append(ev)
             else:
-                torch.distributed.all_reduce(grad, group=self.group)
+                torch.distributed.all_reduce(bucket, group=self.group)
         self.step_count += 1
         _lib.check(_lib.lib().njode_adam_step_f32(
             flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),

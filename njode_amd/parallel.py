@@ -14,9 +14,11 @@ shards embarrassingly because paths interact only through the scalar loss
   per-rank losses and gradients are partial sums;
 * dropout streams are keyed by the global path id (``model.dp_path_offset``), so
   results do not depend on the number of ranks;
-* ``all_reduce(SUM)`` of the flat gradient (P = 10 071 fp32 = 40 KB for the demo
-  model: latency-bound, one bucket, no overlap machinery needed because backward is
-  three kernels), then the identical Adam step on every rank.
+* ONE ``all_reduce(SUM)`` of the bucket [flat gradient (P = 10 071 fp32 = 40 KB for the demo
+  model), the step's scalar loss] (latency-bound, no overlap machinery needed because backward
+  is three kernels), then the identical Adam step on every rank.  The loss ``loss_and_grad``
+  returns is a view of the bucket's last slot: this rank's partial sum until
+  ``FusedAdam.step()``, the global loss afterwards.
 """
 import os
 
@@ -70,6 +72,10 @@ def empty_shard_step(model, fused=True):
     if fused:
         g = model.flat_grad()
         g.zero_()
+        if getattr(model, 'dp_loss_in_bucket', False):
+            slot = model.loss_slot()      # the loss travels in the gradient's bucket
+            slot.zero_()
+            return slot.reshape(())
         return torch.zeros((), dtype=torch.float32, device=g.device)
     dev = None
     for p in model.parameters():

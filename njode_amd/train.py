@@ -161,8 +161,11 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                 shards.append(idx_[lo_:hi_])
             live = [i for i, m_ in enumerate(shards) if len(m_)]
             prepared = [None] * n_steps
-            for i, pr in zip(live, dev_ds.prepare_batches([shards[i] for i in live])):
-                prepared[i] = pr
+            # (a rank whose shard is empty in EVERY step of the epoch -- batch_size < world --
+            # prepares nothing and still joins every step's all-reduce, parallel.empty_shard_step)
+            if live:
+                for i, pr in zip(live, dev_ds.prepare_batches([shards[i] for i in live])):
+                    prepared[i] = pr
         return order, n_steps, prepared
 
     metrics = []
@@ -252,8 +255,13 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                     val_d['times'], val_d['time_ptr'], val_d['X'], val['obs_idx'], delta_t, T,
                     val_d['start_X'], val['n_obs_ot'], stockmodel)]
         eval_time = time.time() - t0
-        train_loss = float(parallel.allreduce_flat_(loss.detach().reshape(1).clone())) \
-            if loss is not None else float('nan')
+        # (fused data-parallel steps all-reduce the loss WITH the gradient: it is global already)
+        if loss is None:
+            train_loss = float('nan')
+        elif fused and world > 1:
+            train_loss = float(loss)
+        else:
+            train_loss = float(parallel.allreduce_flat_(loss.detach().reshape(1).clone()))
         if rank == 0:
             log("epoch {}, weight={:.5f}, train-loss={:.5f}, optimal-eval-loss={:.5f}, "
                 "eval-loss={:.5f}, ".format(model.epoch, model.weight, train_loss,

@@ -57,8 +57,9 @@ def main(out_dir):
         torch.cuda.synchronize()
         return m.flat_parameters().detach().clone(), torch.cat(losses)
 
+    # (the loss is all-reduced WITH the gradient by FusedAdam.step: the values read after the
+    # step are the global losses already)
     p_dp, l_dp = run(world, rank, True)
-    torch.distributed.all_reduce(l_dp)                       # partial losses -> global losses
     gathered = [torch.zeros_like(p_dp) for _ in range(world)]
     torch.distributed.all_gather(gathered, p_dp)
     identical = bool(torch.equal(gathered[0], gathered[1]))

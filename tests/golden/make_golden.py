@@ -26,6 +26,10 @@ Cases:
                           run has to track
   g8_climate_eval (g11, round 3)  climate_train.evaluate_model protocol (:508-566) on a synthetic
                           stand-in: observe up to T_val, predict the held-out measurements
+  g9b_ref_seeded_curves (g12, round 4)  the REFERENCE model trained like-for-like with the build's
+                          harness: same seed-0 20 000-path datasets, split 398, batch 200, the
+                          same shuffled order per epoch, the same initial weights, Adam lr 1e-3 /
+                          wd 5e-4, dropout 0.1 drawn from three torch seeds; eval loss per epoch
   g10 (round 3): g6_w100, g6_none_h50, g6_mixed_nets, g5_w200, g5_climate -- shapes that run on
                           the shape-generic kernels (widths >= 64, nn_desc = None with H = 50,
                           per-network descriptions, the climate shape)
@@ -450,6 +454,67 @@ def g9():
     with open('/root/reference/data/saved_models/model_overview.csv') as f:
         desc = list(csv.reader(f))[1][2]
     save('g9_ref_training_curves', json.loads(desc), arrays)
+
+
+def g12(names=('OrnsteinUhlenbeck', 'BlackScholes'), epochs=12, seeds=(0, 1, 2), batch_size=200):
+    """Like-for-like training curves.  The shipped metric files (g9) come
+    from another realisation of the data and another initialisation; here the reference's OWN
+    model and loop semantics (train.py:488-574: zero_grad, n_obs_ot recounted from obs_idx,
+    model(...) in train mode, loss.backward(), Adam(lr 1e-3, weight_decay 5e-4).step(); per epoch
+    the eval loss of the whole validation set as one batch in eval mode) run on exactly what the
+    build's harness feeds its model: dataset seed 0, train_test_split(seed 398), batch 200, the
+    epoch orders of njode_amd.parallel.epoch_permutation, initial weights = torch.manual_seed(0)
+    + NJODE(...) (stored, so the build starts from the same numbers).  Dropout masks come from
+    torch's generator, seeded 1000 + s after the initialisation, s in `seeds`: the spread over s
+    is the run-to-run noise a dropout-on comparison has to allow for.  Data only."""
+    from njode_amd import data_utils as b_data, parallel as b_par, train as b_train
+    arrays = {}
+    for name in names:
+        paths, obs, nb_obs, hp, sm = ref_dataset(name, 20000, seed=0)
+        dt, T = hp['dt'], hp['maturity']
+        train_idx, val_idx = b_train.split_indices(len(nb_obs), 0.2, 398)
+        val = b_data.collate_arrays(paths[val_idx], obs[val_idx], nb_obs[val_idx], dt)
+        # (the build's stock model: bit-identical conditional expectation, and without the
+        # reference's TypeError at stock_model.py:139 when the last observation is before T)
+        from njode_amd import stock_model as b_stock
+        opt = b_stock.STOCK_MODELS[name](**hp).get_optimal_loss(val['times'], val['time_ptr'], val['X'].numpy(), val['obs_idx'].numpy(),
+                                  dt, T, val['start_X'].numpy(), val['n_obs_ot'].numpy(), weight=0.5)
+        arrays[name + '/optimal_eval_loss'] = np.float64(opt)
+        ev = np.zeros((len(seeds), epochs))
+        tr = np.zeros((len(seeds), epochs))
+        for si, sd in enumerate(seeds):
+            model = build(demo_cfg(dropout=0.1), seed=0)
+            if si == 0:
+                arrays.update({name + '/init/' + k[3:]: v for k, v in sd_arrays(model).items()})
+            optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0005)
+            torch.manual_seed(1000 + sd)
+            for ep in range(1, epochs + 1):
+                model.train()
+                order = train_idx[b_par.epoch_permutation(len(train_idx), ep, 0)]
+                for s_ in range((len(order) + batch_size - 1) // batch_size):
+                    mine = order[s_ * batch_size:(s_ + 1) * batch_size]
+                    b = b_data.collate_arrays(paths[mine], obs[mine], nb_obs[mine], dt)
+                    n_obs_ot = b_data.recount_observations(b['obs_idx'], len(mine))
+                    optimizer.zero_grad()
+                    _, loss = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt, T,
+                                    b['start_X'], n_obs_ot, return_path=False, get_loss=True)
+                    loss.backward()
+                    optimizer.step()
+                model.eval()
+                with torch.no_grad():
+                    _, c_loss = model(val['times'], val['time_ptr'], val['X'], val['obs_idx'], dt, T,
+                                      val['start_X'], val['n_obs_ot'], return_path=False, get_loss=True)
+                ev[si, ep - 1] = float(c_loss)
+                tr[si, ep - 1] = float(loss)
+                model.epoch += 1
+                model.weight_decay_step()
+                print('    {} seed {} epoch {:2d}: train {:.5f} eval {:.5f} (optimal {:.5f})'.format(
+                    name, sd, ep, tr[si, ep - 1], ev[si, ep - 1], opt), flush=True)
+        arrays[name + '/eval_loss'] = ev
+        arrays[name + '/train_loss'] = tr
+    arrays['seeds'] = np.array(seeds)
+    save('g9b_ref_seeded_curves', dict(demo_cfg(dropout=0.1), epochs=epochs, batch_size=batch_size,
+                                       names=list(names)), arrays)
 
 
 def g10():

@@ -50,7 +50,7 @@ def _check_pair(two, p2, one, p1, global_batch, scaling):
     assert two['n_gpus'] == 2 and two['rccl_world'] == 2
     assert two['scaling'] == scaling
     assert two['collective_backend'].startswith('gloo')        # shared-GPU self-test
-    assert two['allreduce_floats'] == 10071
+    assert two['allreduce_floats'] == 10071 + 1                 # gradient + the scalar loss, one bucket
     assert two['allreduce_ms'] is not None and two['allreduce_ms'] > 0
     assert len(two['ms_per_step_by_rank']) == 2
     assert two['params_identical_across_ranks'] is True

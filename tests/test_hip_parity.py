@@ -11,6 +11,7 @@ from golden_util import Golden, all_model_cases
 from hip_util import (ATOL, GRAD_REL_L2, LOSS_RTOL, RTOL, RTOL_LONG, bs_batch, demo_cfg, grads_by_name,
                       hip_forward, hip_model, oracle_forward, rel_l2, to_dev)
 from njode_amd import _lib, data_utils, models, stock_model
+from oracle import njode_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -127,6 +128,62 @@ def test_adam_steps_match_reference(fused):
                 np.testing.assert_allclose(sd[k].cpu().numpy(), ref, atol=2e-5, rtol=1e-4,
                                            err_msg='{} step {}'.format(k, step))
     np.testing.assert_allclose(losses, g['adam_losses'], rtol=2e-4)
+
+
+def test_bias_free_model_trains_like_the_reference():
+    """bias=False (models.py:140-166: Linear layers without a bias).  The C ABI keeps a zero
+    slot per absent bias and the kernels write its gradient; the fused optimizer must not treat
+    it as a parameter.  Five steps of FusedAdam == five steps of
+    torch.optim.Adam on the autograd route == five steps of torch.optim.Adam on the oracle,
+    and every bias slot is still exactly 0."""
+    g = Golden('g2_bs_grads_B64')
+    cfg = dict(g.cfg, bias=False)
+    sd0 = {k: v for k, v in g.state_dict().items() if not k.endswith('bias')}
+    b_host = g.batch()
+    b = to_dev(b_host)
+    n_obs_ot = data_utils.recount_observations(b_host['obs_idx'], 64)
+    args = (b['times'], b['time_ptr'], b['X'], b['obs_idx'], g.delta_t, g.T, b['start_X'],
+            n_obs_ot.cuda())
+    # oracle: plain autograd + torch Adam on the CPU
+    o = njode_oracle.make_oracle(cfg)
+    o.training = True
+    po = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    opt_o = torch.optim.Adam(list(po.values()), lr=1e-3, weight_decay=0.0005)
+    losses_o = []
+    for _ in range(5):
+        opt_o.zero_grad()
+        out = o.forward(po, b_host['times'], b_host['time_ptr'], b_host['X'], b_host['obs_idx'],
+                        g.delta_t, g.T, b_host['start_X'], n_obs_ot)
+        out[1].backward()
+        opt_o.step()
+        losses_o.append(float(out[1]))
+    results = {}
+    for fused in (True, False):
+        m = hip_model(cfg, sd0).train()
+        assert not any(k.endswith('bias') for k in m.state_dict())
+        opt = (models.FusedAdam(m, lr=1e-3, weight_decay=0.0005) if fused
+               else torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0005))
+        losses = []
+        for _ in range(5):
+            opt.zero_grad()
+            if fused:
+                _, loss = m.loss_and_grad(*args)
+            else:
+                _, loss = m(*args)
+                loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        flat = m.flat_parameters()
+        absent = m._flat_present == 0
+        assert int(absent.sum()) == (50 + 50 + 10) * 2 + (50 + 50 + 1)
+        assert float(flat[absent].abs().max()) == 0.0, 'a bias slot moved'
+        results[fused] = (losses, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()})
+        np.testing.assert_allclose(losses, losses_o, rtol=2e-4)
+        for k, v in po.items():
+            np.testing.assert_allclose(results[fused][1][k], v.detach().numpy(), atol=2e-5, rtol=1e-4,
+                                       err_msg='{} fused={}'.format(k, fused))
+    for k in results[True][1]:
+        np.testing.assert_allclose(results[True][1][k], results[False][1][k], atol=2e-6, rtol=1e-5)
 
 
 @pytest.mark.parametrize('tag,name', [('BS', 'BlackScholes'), ('Heston', 'Heston'),

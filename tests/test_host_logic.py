@@ -4,6 +4,7 @@ every symbol include/njode_hip.h declares (no compute without a GPU)."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -276,3 +277,61 @@ def test_torch_library_operator_is_registered_with_a_fake_implementation():
             torch.empty(5, dtype=torch.float64), torch.empty(6, dtype=torch.int64), 0.01, 1.0,
             mid, True, False, False)
     assert tuple(hT.shape) == (7, 10) and tuple(loss.shape) == (1,) and cid.dim() == 0
+
+
+# ---- bench.py --gpus N without a launcher: no GPU needed for these --------
+def _run_bench(args, env_extra, timeout=300):
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(repo, 'bench.py')] + args, env=env, cwd=repo,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_gpu_count_comes_from_the_kfd_topology_not_the_runtime(tmp_path, monkeypatch):
+    import bench
+    root = tmp_path / 'nodes'
+    for i, simd in enumerate((0, 1024, 1024, 1024)):          # one CPU node, three GPUs
+        (root / str(i)).mkdir(parents=True)
+        (root / str(i) / 'properties').write_text('cpu_cores_count 8\nsimd_count {}\n'.format(simd))
+    real_listdir, real_open = os.listdir, open
+
+    def fake_listdir(path):
+        return real_listdir(str(root)) if path == '/sys/class/kfd/kfd/topology/nodes' else real_listdir(path)
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith('/sys/class/kfd/kfd/topology/nodes/'):
+            path = str(root) + path[len('/sys/class/kfd/kfd/topology/nodes'):]
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(os, 'listdir', fake_listdir)
+    monkeypatch.setattr('builtins.open', fake_open)
+    for v in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.count_gpus_without_runtime() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,2')
+    assert bench.count_gpus_without_runtime() == 2
+
+
+def test_self_spawned_ranks_that_fail_are_reported_with_their_stderr():
+    """No GPU here: both ranks die at torch.cuda.set_device -- the parent must come back with
+    their exit code and the tail of their stderr instead of hanging or hiding it."""
+    p = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--rank-timeout', '240'],
+                   {'NJODE_BENCH_SHARE_GPU': '1'})
+    if p.returncode == 0:
+        pytest.skip('this box has a GPU: the ranks ran')
+    assert p.returncode not in (0, 124), p.stderr[-2000:]
+    assert 'ranks exited with code' in p.stderr
+    assert '  | ' in p.stderr                      # the relayed tail
+
+
+def test_self_spawned_ranks_are_killed_after_the_rank_timeout():
+    import time
+    t0 = time.time()
+    p = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--rank-timeout', '0.2'],
+                   {'NJODE_BENCH_SHARE_GPU': '1'})
+    assert p.returncode == 124, (p.returncode, p.stderr[-2000:])
+    assert 'process group killed' in p.stderr
+    assert time.time() - t0 < 60
