@@ -86,6 +86,7 @@ struct KArgs {
   // base16_s = prefix sum of the per-step chain counts rounded up to 16
   const long long* base16_s;
   float* act;
+  float* dact;   // delta records of the backward's four-wave role (same layout as act)
   // intermediates
   float* h0row;
   float* h0start;
@@ -133,6 +134,7 @@ struct KArgs {
   // ... mixed kernels: the first n_split_* blocks run the longest tiles four waves per tile,
   // the other blocks one wave per tile (njode_mfma_split.h); grid sizes
   int n_split_blocks, n_blocks_bwd, n_split_fwd, n_blocks_fwd;
+  int bwd_delta;   // four-wave role of the backward: delta sweep + weight-gradient pass (1) or the fused form (0)
   DropCtx dc;
   float keep;
 };

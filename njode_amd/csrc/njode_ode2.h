@@ -510,6 +510,85 @@ template <class C> struct OdeBwdActLds {
 #define NJ_BWD_ABL 0
 #endif
 #define BWD_ABL(bit) ((NJ_BWD_ABL) & (bit))
+// flush of a 256-thread block's four workers (the bulk role; the four-wave role's dW pass): their
+// register tiles are summed through LDS in fixed order and stored as ONE slab row
+template <class C, bool DROP>
+NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<C>::W + 1 + 15) / 16],
+                       f32x4 (&G2)[MF<C>::MT1][(MF<C>::W + 1 + 15) / 16],
+                       f32x4 (&G1)[MF<C>::MT1][(MF<C>::IN0 + 1 + 15) / 16], int slab_row) {
+  using M = MF<C>;
+  using NL = typename C::Ode;
+  constexpr int NT1 = (M::W + 1 + 15) / 16, NT0 = (M::IN0 + 1 + 15) / 16;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  // ---- flush (as ode_bwd_single): one slab row per block
+  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
+  static_assert(3 * NG * 64 * 4 <= OdeBwdActLds<C>::FLOATS, "tile reduction does not fit the LDS");
+  __syncthreads();
+  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
+  auto for_tiles = [&](auto f) {
+    int i = 0;
+#pragma unroll
+    for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
+#pragma unroll
+    for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT0; ++nt) f(G1[mt][nt], i++);
+  };
+  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
+  __syncthreads();
+  if (wv != 0) return;
+  for_tiles([&](f32x4& t, int i) {
+    t += red[(0 * NG + i) * 64 + lane];
+    t += red[(1 * NG + i) * 64 + lane];
+    t += red[(2 * NG + i) * 64 + lane];
+  });
+  // the stored activations carry no inverted-dropout factor: it goes on once, here
+  const float ik = DROP ? a.dc.inv_keep : 1.0f;
+  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
+  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
+        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < M::W) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W2[uo * M::W + ui] = ik * G2[mt][nt][r];
+          else if (ui == M::W) b2[uo] = G2[mt][nt][r];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT0; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::IN0) W1[uo * M::IN0 + M::col0(ui)] = G1[mt][nt][r];
+          else if (ui == M::IN0) b1[uo] = G1[mt][nt][r];
+        }
+      }
+    }
+#pragma unroll
+  for (int mt = 0; mt < M::MTH; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < C::H) {
+#pragma unroll
+        for (int nt = 0; nt < NT1; ++nt) {
+          const int ui = 16 * nt + c;
+          if (ui < M::W) W3[uo * M::W + ui] = ik * G3[mt][nt][r];
+          else if (ui == M::W) b3[uo] = G3[mt][nt][r];
+        }
+      }
+    }
+}
+
 template <class C, bool DROP>
 NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
                             int slab_row) {
@@ -686,73 +765,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   }
 
   if (BWD_ABL(128)) return;
-  // ---- flush (as ode_bwd_single): one slab row per block
-  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
-  static_assert(3 * NG * 64 * 4 <= OdeBwdActLds<C>::FLOATS, "tile reduction does not fit the LDS");
-  __syncthreads();
-  f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
-  auto for_tiles = [&](auto f) {
-    int i = 0;
-#pragma unroll
-    for (int mt = 0; mt < M::MTH; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
-#pragma unroll
-    for (int mt = 0; mt < M::MT1; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
-#pragma unroll
-    for (int mt = 0; mt < M::MT1; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT0; ++nt) f(G1[mt][nt], i++);
-  };
-  if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
-  __syncthreads();
-  if (wv != 0) return;
-  for_tiles([&](f32x4& t, int i) {
-    t += red[(0 * NG + i) * 64 + lane];
-    t += red[(1 * NG + i) * 64 + lane];
-    t += red[(2 * NG + i) * 64 + lane];
-  });
-  // the stored activations carry no inverted-dropout factor: it goes on once, here
-  const float ik = DROP ? a.dc.inv_keep : 1.0f;
-  float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
-  float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
-        *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
-#pragma unroll
-  for (int mt = 0; mt < M::MT1; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int uo = 16 * mt + 4 * g + r;
-      if (uo < M::W) {
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) {
-          const int ui = 16 * nt + c;
-          if (ui < M::W) W2[uo * M::W + ui] = ik * G2[mt][nt][r];
-          else if (ui == M::W) b2[uo] = G2[mt][nt][r];
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT0; ++nt) {
-          const int ui = 16 * nt + c;
-          if (ui < M::IN0) W1[uo * M::IN0 + M::col0(ui)] = G1[mt][nt][r];
-          else if (ui == M::IN0) b1[uo] = G1[mt][nt][r];
-        }
-      }
-    }
-#pragma unroll
-  for (int mt = 0; mt < M::MTH; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int uo = 16 * mt + 4 * g + r;
-      if (uo < C::H) {
-#pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) {
-          const int ui = 16 * nt + c;
-          if (ui < M::W) W3[uo * M::W + ui] = ik * G3[mt][nt][r];
-          else if (ui == M::W) b3[uo] = G3[mt][nt][r];
-        }
-      }
-    }
+  ode3_flush<C, DROP>(a, lds_raw, G3, G2, G1, slab_row);
 }
 
 
