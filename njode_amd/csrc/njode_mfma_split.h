@@ -597,31 +597,35 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
         a1l[QBb % 4] = g == GBb ? 1.0f : a1l[QBb % 4];
         a2l[QBb % 4] = g == GBb ? 1.0f : a2l[QBb % 4];
       }
+      // (round 4: no barrier here.  X1 -- a1 of all four tiles -- is only read by the dW2
+      // product behind barrier (b), and it is only rewritten behind barrier (c), by when every
+      // wave has finished that product: the all-gather of a1 rides on the barriers the delta
+      // chain needs anyway)
       split_put(X1, a1l, g, c, w);
-      block_lds_barrier();                               // (a) a1 of all four tiles is in X1
 
       // ---- layer 3: delta3 = dt * lam; dW3 column tile w; W3^T delta3 for the own units
       float d3[M::QH];
 #pragma unroll
       for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
+      f32x4 acc = z;
+#pragma unroll
+      for (int q = 0; q < M::QH; ++q) acc = mfma4(F.B3[q], d3[q], acc);
       img_write<M::QH>(imgD3, d3, g, c);
 #pragma unroll
       for (int r = 0; r < 4; ++r) imgA2[(4 * r + g) * IMG_STRIDE + c] = a2l[r];
       img_write<M::Q0>(imgB0, b0, g, c);
-      f32x4 acc = z;
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) acc = mfma4(F.B3[q], d3[q], acc);
       float d2l[4], d1l[4];
       split_delta_stored<C, DROP>(acc, a2u, d2l, ik, g, w);
       split_put(X2, d2l, g, c, w);
-      wave_lds_sync();
-      dw_accumulate<1, 1>(imgD3, imgA2, G3, g, c);
-      block_lds_barrier();                             // (b) d2 of all four tiles is in X2
+      block_lds_barrier();                             // (b) d2 (and a1) of all four tiles are in X2 (X1)
 
-      // ---- layer 2: W2^T delta2 for the own units; dW2 row tile w
+      // ---- layer 2: W2^T delta2 for the own units; dW3 column tile w, dW2 row tile w
       float d2[M::QW];
       split_get<M::QW>(X2, d2, g, c);
       __builtin_amdgcn_sched_barrier(0);   // (as in split_hidden_layers)
+      // (the dW3 product -- its images are this wave's own, written before the barrier -- runs
+      // while the gather of d2 is in flight, not in front of the barrier)
+      dw_accumulate<1, 1>(imgD3, imgA2, G3, g, c);
       f32x4 acc0 = z, acc1 = z;
 #pragma unroll
       for (int q = 0; q < M::QW; q += 2) {
