@@ -68,15 +68,45 @@ __global__ void k_pack_all(const float* __restrict__ P, float* __restrict__ frag
   else if (idx < 2 * N + NE) pack_net_value<typename C::Enc, ES>(P + C::OFF_ENC, frag_enc, idx - 2 * N);
   else if (idx < 2 * N + NE + ND) pack_net_value<typename C::Dec, DS>(P + C::OFF_DEC, frag_dec, idx - 2 * N - NE);
 }
+// ... and, in the same launch, the keep bits of the ODE forward's four-wave role (blocks behind the
+// n_pack packing blocks: njode_mfma_split.h, drop_bits_tile_steps): no launch, no stream hop of
+// their own, parallel over the chip, before the forward kernel starts
+template <class C, class ES, class DS>
+__global__ void k_pack_all_bits(KArgs a, int n_pack) {
+  if ((int)blockIdx.x < n_pack) {
+    constexpr int N = MF<C>::NALL * 64, NE = ES::NALL * 64, ND = DS::NALL * 64;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < N) a.frag[idx] = ode_frag_value<C>(a.P, idx, 1.0f, 1.0f);
+    else if (idx < 2 * N) a.frag2[idx - N] = ode_frag_value<C>(a.P, idx - N, Ode2Scale<C>::S, a.dc.inv_keep);
+    else if (idx < 2 * N + NE) pack_net_value<typename C::Enc, ES>(a.P + C::OFF_ENC, a.frag_enc, idx - 2 * N);
+    else if (idx < 2 * N + NE + ND) pack_net_value<typename C::Dec, DS>(a.P + C::OFF_DEC, a.frag_dec, idx - 2 * N - NE);
+  } else {
+    if constexpr (HAS_SPLIT) {
+      const int nb = (int)gridDim.x - n_pack;
+      drop_bits_tile_steps<C>(a, ((int)blockIdx.x - n_pack) * 4 + (threadIdx.x >> 6), nb * 4);
+    }
+  }
+}
 
 // MFMA launches live in templates on the configuration so that `if constexpr` really
 // discards them for shapes the matrix-core kernels are not written for
-template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st) {
+// (bits: the plan is complete on this stream -- the call has no helper stream -- and the forward
+// will draw dropout masks: KArgs::dbits_ready)
+template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st, bool bits = false) {
   if constexpr (HAS_MFMA) {
     using ES = typename EncS<CC>::type;
     using DS = typename DecS<CC>::type;
-    k_pack_all<CC, ES, DS><<<cdiv((2 * MF<CC>::NALL + ES::NALL + DS::NALL) * 64, 256), 256, 0, st>>>(
-        a.P, a.frag, a.frag2, a.frag_enc, a.frag_dec, a.dc.inv_keep);
+    const int n_pack = cdiv((2 * MF<CC>::NALL + ES::NALL + DS::NALL) * 64, 256);
+    if (bits) {
+      // one wave per 8 Euler steps of a four-wide tile; the number of such tiles is known on the
+      // device only: enough waves for the small plans (every tile four-wide), a persistent
+      // grid for the large ones
+      const long long work = (long long)cdiv(a.n_obs, 16) * cdiv(a.K > 0 ? a.K : 1, 8);
+      const int nb = (int)(work / 4 + 1 < 1024 ? work / 4 + 1 : 1024);
+      k_pack_all_bits<CC, ES, DS><<<n_pack + nb, 256, 0, st>>>(a, n_pack);
+    } else {
+      k_pack_all<CC, ES, DS><<<n_pack, 256, 0, st>>>(a.P, a.frag, a.frag2, a.frag_enc, a.frag_dec, a.dc.inv_keep);
+    }
   }
 }
 template <class CC, bool DROP> static void launch_mfma_enc(const KArgs& a, hipStream_t st) {
@@ -163,9 +193,19 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     const SideInfo* side = (const SideInfo*)a.plan_ready;
     hipStream_t s2 = side ? side->st : st;
     if (side) (void)hipStreamWaitEvent(s2, side->e0, 0);
+    // (a copy of the arguments: whether the keep bits are drawn ahead is decided here)
+    KArgs ab = a;
     if constexpr (ODE == ODE_MFMA) {
+      static const bool bits_off = getenv("NJODE_DROP_BITS_AHEAD") && atoi(getenv("NJODE_DROP_BITS_AHEAD")) == 0;
+      // (plans whose every tile runs four waves wide, i.e. small batches: there the forward IS the
+      // chain of its longest tile; in the mixed kernel of a large plan the four-wave blocks are
+      // ~10 % of the work and the extra blocks of this launch cost more than they save:
+      // 20 000 paths, k_pack_all 7.5 -> 12.3 us for ~1.5 us off k_ode_fwd_mixed)
+      const bool bits = DROP && HAS_SPLIT && a.ode_split && a.dbits && !side && !bits_off &&
+                        a.n_split_fwd == a.n_blocks_fwd;
+      ab.dbits_ready = bits ? 1 : 0;
       ProfScope ps("k_pack_all", s2);
-      launch_pack_frags<C>(a, s2);
+      launch_pack_frags<C>(ab, s2, bits);
     }
     {
       ProfScope ps(ODE == ODE_MFMA ? "k_encode_rows_mfma" : "k_encode_rows", s2);
@@ -179,7 +219,7 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     {   // (the names are the launched kernels', as rocprofv3 lists them)
       ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_mixed" : "k_ode_fwd_mfma")
                                    : "k_ode_fwd_items", st);
-      launch_ode_fwd<DROP, false, ODE>(a, st);
+      launch_ode_fwd<DROP, false, ODE>(ab, st);
     }
     if (tails) {
       ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_split.tails" : "k_ode_fwd_mfma.tails")
@@ -286,7 +326,7 @@ template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) 
 template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_Q4) {
     if (!a.want_path && lock4_on() && (!a.save_traj || a.lact)) {
-      k_paths_fwd_q4<CC, DROP><<<cdiv(a.B, 16), 256, 0, st>>>(a);
+      k_paths_fwd_q4<CC, DROP><<<cdiv(a.B, a.q4_pt), 256, 0, st>>>(a);
       return;
     }
   }
@@ -326,7 +366,7 @@ template <class CC, bool DROP> static void lock_bwd_mfma(const KArgs& a, hipStre
       bool q4 = false;
       if constexpr (HAS_Q4) {
         if (lock4_on() && a.lact) {   // (lact: the saving forward was k_paths_fwd_q4)
-          k_paths_bwd_adj_q4<CC, DROP><<<cdiv(a.B, 16), 256, 0, st>>>(a);
+          k_paths_bwd_adj_q4<CC, DROP><<<cdiv(a.B, a.q4_pt), 256, 0, st>>>(a);
           q4 = true;
         }
       }

@@ -455,8 +455,10 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   __syncthreads();
 
   const bool LOSS = a.want_loss != 0, SAVE = a.save_traj != 0;
-  const int b0i = blockIdx.x * 16 + c;
-  const bool valid = b0i < a.B;
+  // (round 4: a tile holds a.q4_pt <= 16 paths -- see q4_paths_per_tile, njode_api.hip; the
+  // other lanes shadow a valid path and store nothing)
+  const int b0i = blockIdx.x * a.q4_pt + c;
+  const bool valid = c < a.q4_pt && b0i < a.B;
   const int b = valid ? b0i : a.B - 1;
   const unsigned long long gid = a.gid0 + b;
   float* const trash = a.trash + threadIdx.x;
@@ -755,8 +757,10 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   Fd.load(a.frag_dec, w, lane, 0);
   __syncthreads();
 
-  const int b0i = blockIdx.x * 16 + c;
-  const bool valid = b0i < a.B;
+  // (round 4: a tile holds a.q4_pt <= 16 paths -- see q4_paths_per_tile, njode_api.hip; the
+  // other lanes shadow a valid path and store nothing)
+  const int b0i = blockIdx.x * a.q4_pt + c;
+  const bool valid = c < a.q4_pt && b0i < a.B;
   const int b = valid ? b0i : a.B - 1;
   const unsigned long long gid = a.gid0 + b;
   float* const trash = a.trash + threadIdx.x;

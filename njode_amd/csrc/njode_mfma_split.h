@@ -102,6 +102,45 @@ NJ_DEV void split_keep_bits(const KArgs& a, int b, int k, int g, int w, uint32_t
   }
 }
 
+// The keep bits of the four-wave forward AHEAD of the kernel.  In the four-wave role a Euler
+// step is a chain of two exchanges on four SIMDs that each run ONE wave: every instruction of the
+// step is on its critical path, and split_keep_bits -- three hash rounds, up to eleven serial
+// xorshift words to reach the wave's own four, the bit assembly: ~130 VALU instructions -- was a
+// fifth of the step although it depends on nothing the chain computes.  drop_bits_tile_steps
+// draws, for the tile-steps of the T longest tiles, the bits of ALL four waves at once (the whole
+// lane-group stream of the one-wave kernels: k1 | k2 << 16, bit q = register q = unit 4q + g),
+// one dword per lane; it runs in spare blocks of the fragment-pack launch, i.e. in parallel over
+// the chip and off every chain.  The forward then loads one dword per step (one step ahead).
+// Same masks, bit for bit, as split_keep_bits / the one-wave kernels.
+template <class C>
+NJ_DEV void drop_bits_tile_steps(const KArgs& a, int worker, int n_workers) {
+  using M = MF<C>;
+  constexpr int CH = 8;                                  // Euler steps per work item
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int T = (int)a.base_s[a.K + 2];                  // split point of the forward
+  const int n_ch = (a.K + CH - 1) / CH;
+  const long long n_work = (long long)T * n_ch;
+  for (long long i = worker; i < n_work; i += n_workers) {
+    const int tile = (int)(i / n_ch), s0 = (int)(i % n_ch) * CH;
+    const int j = tile * 16 + c;
+    const bool valid = j < a.n_obs;
+    const int r = a.order[valid ? j : 0];
+    const int n = valid ? a.item_len[r] : 0;
+    const int nmax = uniform(wave_max(n));
+    if (s0 >= nmax) continue;
+    const int b = a.obs_idx[r], kbeg = a.item_kbeg[r];
+    const unsigned long long gid = a.gid0 + b;
+    for (int s = s0; s < s0 + CH && s < nmax; ++s) {
+      const int k = s < n ? kbeg + s : 0;
+      uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
+                               (uint32_t)k, NET_ODE);
+      const uint32_t k1 = keep_bits<M::Q1>(st, a.dc.thr16);
+      const uint32_t k2 = keep_bits<M::Q1>(st, a.dc.thr16);
+      a.dbits[(size_t)(sload_ll(a.base16_s, s) / 16 + tile) * 64 + lane] = k1 | (k2 << 16);
+    }
+  }
+}
+
 // activation of the own tile: al[r] = act(acc[r]) (+ dropout); the bias unit (unit W) is 1
 // (au: the form the forward stores for the backward -- no 1 / (1 - p), a dropped unit as -0.0f)
 template <class C, bool DROP>
@@ -269,6 +308,7 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
   In0Const<C> K0;
   K0.init(g);
   __syncthreads();
+  const bool bits_ahead = DROP && !TAIL && a.dbits_ready != 0;   // (wave-uniform)
 
   const int n_items = TAIL ? a.B : a.n_obs;
   const int n_tiles = tile1 - tile0;
@@ -290,30 +330,41 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
     }
     const int nmax = uniform(wave_max(it.n));   // (scalar step loop: see ode2_fwd_single)
     float dt_r = 0.0f, t_r = 0.0f;
+    uint32_t kb_r = 0;
     long long b16_n = 0;
     if (nmax > 0) {
       const int k0 = it.n > 0 ? it.kbeg : 0;
       dt_r = a.step_dt[k0];
       t_r = a.step_t[k0];
-      b16_n = SAVE ? sload_ll(a.base16_s, 0) : 0;
+      b16_n = (SAVE || bits_ahead) ? sload_ll(a.base16_s, 0) : 0;
+      if (bits_ahead) kb_r = a.dbits[(size_t)(b16_n / 16 + tile) * 64 + lane];
     }
     vm_drain();
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
       const int k = active ? it.kbeg + s : 0;
       const float dt = active ? dt_r : 0.0f, t = t_r;
+      const uint32_t kb = kb_r;
       const long long b16 = b16_n;
       {
         const int sn = s + 1 < nmax ? s + 1 : s;
         const int kn = sn < it.n ? it.kbeg + sn : 0;
         dt_r = a.step_dt[kn];
         t_r = a.step_t[kn];
-        if constexpr (SAVE) b16_n = sload_ll(a.base16_s, sn);
+        if (SAVE || bits_ahead) b16_n = sload_ll(a.base16_s, sn);
+        if (bits_ahead) kb_r = a.dbits[(size_t)(b16_n / 16 + tile) * 64 + lane];
       }
       float b0[M::Q0], a1l[4], a2l[4], a1u[4], a2u[4];
       in0_fill_c<C, 0>(b0, h, it.tx, it.tau, t - it.tau, g, K0);
-      uint32_t k1, k2;
-      split_keep_bits<C, DROP>(a, it.b, k, g, w, k1, k2);
+      uint32_t k1 = 0, k2 = 0;
+      if constexpr (DROP) {
+        if (bits_ahead) {                     // (uniform) drawn ahead: drop_bits_tile_steps
+          k1 = (kb >> (4 * w)) & 15u;
+          k2 = (kb >> (16 + 4 * w)) & 15u;
+        } else {
+          split_keep_bits<C, DROP>(a, it.b, k, g, w, k1, k2);
+        }
+      }
       split_hidden_layers<C, DROP, false>(F, X1, b0, a1l, a2l, a1u, a2u, k1, k2, a.dc.inv_keep, g, c, w);
       if constexpr (SAVE) split_rec_store<C>(rec_block<C>(a.act, b16, tile), a.trash, lane, w, a1u, a2u, h);
       f32x4 part = {0.f, 0.f, 0.f, 0.f};

@@ -70,7 +70,7 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
           evaluate=False, shuffle_seed=0, log=print, max_steps_per_epoch=None,
           device_collate=False, model_path=None, model_id=1, save_every=1,
           resume_training=False, load_best=False, plan_ahead=True, plan_ahead_min=0,
-          **options):
+          init_state=None, **options):
     """Train on an in-memory dataset ``(stock_paths, observed_dates, nb_obs)`` with
     ``metadata`` as returned by ``data_utils.create_dataset``.  Returns
     ``(model, metrics)`` with one row of ``METR_COLUMNS`` per epoch.
@@ -79,7 +79,9 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
     GPU collate (``device_data.DeviceDataset``): same batches bit for bit, without the
     per-step host collate and host-to-device copies.  ``plan_ahead`` (fused loop): collate one
     batch ahead and, for local batches of 4 096 paths or more, build its execution plan beside
-    the current step (same results bit for bit)."""
+    the current step (same results bit for bit).  ``init_state``: a state_dict to start from
+    instead of the seed-0 initialisation; ``dropout_seed`` (an option of the model) selects the
+    dropout stream."""
     stock_paths, observed_dates, nb_obs = dataset_arrays
     delta_t, T = metadata['dt'], metadata['maturity']
     input_size = output_size = metadata['dimension']
@@ -97,6 +99,8 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
                          readout_nn, enc_nn, use_rnn, bias=bias, dropout_rate=dropout_rate,
                          solver=solver, weight=weight, weight_decay=weight_decay,
                          options=model_opts).to(device)
+    if init_state is not None:     # start from given weights (like-for-like runs against the reference)
+        model.load_state_dict(init_state)
     parallel.broadcast_parameters_(model.flat_parameters())
     if fused:
         optimizer = models.FusedAdam(model, lr=learning_rate, weight_decay=0.0005,

@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(REPO, 'tools'))
 EPOCHS = 30
 # absolute band on the excess ratio; observed gaps (profiles/r03_convergence_*.jsonl):
 # BS -0.02 ... -0.22 (the build converges faster), OU +0.04 ... +0.14, Heston -0.013 ... -0.025
-BAND = {'BlackScholes': 0.10, 'OrnsteinUhlenbeck': 0.25, 'Heston': 0.03}
+BAND = {'BlackScholes': 0.10, 'OrnsteinUhlenbeck': 0.18, 'Heston': 0.03}
 UNDERCUT = {'BlackScholes': 0.02, 'OrnsteinUhlenbeck': 0.02, 'Heston': 0.05}
 
 
@@ -52,3 +52,25 @@ def test_training_tracks_the_reference_curve(name):
     # ends between the optimal loss and the reference's value at this epoch + band
     assert ev[-1] >= opt * (1.0 - UNDERCUT[name]), (ev[-1], opt)
     assert ex[-1] <= ref['excess'][EPOCHS - 1] + BAND[name]
+
+
+@pytest.mark.parametrize('name', ['OrnsteinUhlenbeck', 'BlackScholes'])
+def test_training_matches_the_reference_trained_like_for_like(name):
+    """VERDICT r3 item 3a.  The shipped curves above come from another realisation of the data and
+    another initialisation; `g9b_ref_seeded_curves` is the REFERENCE's own model and loop
+    (train.py:488-574) run on exactly what this harness feeds its model -- seed-0 dataset, split
+    398, batch 200, the same epoch orders, the same initial weights, Adam lr 1e-3 / wd 5e-4,
+    dropout 0.1 -- for 12 epochs and three dropout seeds.  The only thing that differs between the
+    two runs is the dropout stream (torch's generator there, the kernels' counter-based stream
+    here), so the seed AVERAGES must agree: per epoch, the build's mean excess over the optimal
+    loss within the reference's seed spread + 10 % of the reference's mean excess."""
+    import convergence_run
+    mine, ref, _ = convergence_run.run_seeded(name)
+    assert mine.shape == ref.shape and np.isfinite(mine).all()
+    m_b, m_r = mine.mean(axis=0), ref.mean(axis=0)
+    spread = ref.max(axis=0) - ref.min(axis=0)
+    band = spread + 0.10 * np.abs(m_r)
+    worst = np.abs(m_b - m_r) / band
+    assert (worst[1:] <= 1.0).all(), (name, np.round(m_b, 3), np.round(m_r, 3), np.round(band, 3))
+    # epoch 1 (one pass over a fresh model, the steepest part of the curve): 20 %
+    assert abs(m_b[0] - m_r[0]) <= 0.2 * m_r[0]

@@ -41,6 +41,34 @@ def run(name='BlackScholes', epochs=30, batch_size=200, device_collate=True, log
     return rows, ref
 
 
+def run_seeded(name='OrnsteinUhlenbeck', seeds=(0, 1, 2), log=None):
+    """Like-for-like against tests/golden/g9b_ref_seeded_curves.npz (the REFERENCE model trained
+    on this harness' own recipe: same dataset, split, batches, epoch orders and initial weights,
+    dropout masks from three torch seeds).  Returns (excess[seed][epoch] of the build, the same
+    of the reference, optimal loss): dropout streams differ (torch's generator vs the kernels'
+    counter-based one), so the comparison is between seed averages."""
+    import torch
+    from golden_util import Golden
+    from njode_amd import data_utils, train
+    g = Golden('g9b_ref_seeded_curves')
+    epochs = int(g.cfg['epochs'])
+    hp = dict(data_utils.hyperparam_default, nb_paths=20000)
+    paths, obs, nb_obs, meta = data_utils.create_dataset(name, hp, seed=0)
+    init = {k[len(name) + 6:]: torch.from_numpy(g[k]) for k in g.z.files if k.startswith(name + '/init/')}
+    ref_opt = float(g[name + '/optimal_eval_loss'])
+    out = []
+    for sd in seeds:
+        _, metrics = train.train((paths, obs, nb_obs), meta, epochs=epochs, batch_size=int(g.cfg['batch_size']),
+                                 learning_rate=1e-3, dropout_rate=0.1, seed=398, test_size=0.2,
+                                 log=log or (lambda s: None), device_collate=True, init_state=init,
+                                 dropout_seed=1000 + int(sd))
+        opt = metrics[0][5]
+        assert abs(opt - ref_opt) <= 1e-6 * abs(ref_opt), (opt, ref_opt)     # the same validation set
+        out.append([(m[4] - opt) / abs(opt) for m in metrics])
+    ref = (g[name + '/eval_loss'] - ref_opt) / abs(ref_opt)
+    return np.array(out), ref, ref_opt
+
+
 if __name__ == '__main__':
     name = sys.argv[1] if len(sys.argv) > 1 else 'BlackScholes'
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 30
