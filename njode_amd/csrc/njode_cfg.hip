@@ -326,7 +326,17 @@ template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) 
 template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_Q4) {
     if (!a.want_path && lock4_on() && (!a.save_traj || a.lact)) {
-      k_paths_fwd_q4<CC, DROP><<<cdiv(a.B, a.q4_pt), 256, 0, st>>>(a);
+      const int n_tiles = cdiv(a.B, a.q4_pt);
+      KArgs ab = a;
+      static const bool bits_off = getenv("NJODE_DROP_BITS_AHEAD") && atoi(getenv("NJODE_DROP_BITS_AHEAD")) == 0;
+      if (DROP && a.dbits && a.dbits_row && !bits_off) {
+        // the keep bits of every evaluation of the forward, drawn ahead in parallel over the chip
+        const long long items = (long long)a.K * n_tiles;
+        const int nb = (int)(items / 4 + 1 < 2048 ? items / 4 + 1 : 2048);
+        k_q4_bits<CC><<<nb, 256, 0, st>>>(a, n_tiles);
+        ab.dbits_ready = 1;
+      }
+      k_paths_fwd_q4<CC, DROP><<<n_tiles, 256, 0, st>>>(ab);
       return;
     }
   }

@@ -86,9 +86,11 @@ struct KArgs {
   // base16_s = prefix sum of the per-step chain counts rounded up to 16
   const long long* base16_s;
   float* act;
-  float* dact;   // delta records of the backward's four-wave role (same layout as act)
   uint32_t* dbits;   // keep bits of the forward's four-wave role: [tile-step][lane], k1 | k2 << 16
   int dbits_ready;   // ... were written ahead of the ODE forward (by the fragment-pack launch)
+  // masked lockstep forward (njode_mfma_lock4.h): dbits = [Euler step][tile][lane] words of the ODE
+  // network, dbits_row = [row][3 evaluations][4 lane groups] words of the jumps' networks
+  uint32_t* dbits_row;
   // intermediates
   float* h0row;
   float* h0start;
@@ -137,7 +139,6 @@ struct KArgs {
   // the other blocks one wave per tile (njode_mfma_split.h); grid sizes
   int n_split_blocks, n_blocks_bwd, n_split_fwd, n_blocks_fwd;
   int q4_pt;       // masked lockstep kernels (njode_mfma_lock4.h): paths per 16-lane tile
-  int bwd_delta;   // four-wave role of the backward: delta sweep + weight-gradient pass (1) or the fused form (0)
   DropCtx dc;
   float keep;
 };

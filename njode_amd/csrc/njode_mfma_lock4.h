@@ -335,6 +335,44 @@ NJ_DEV void q4_ode_keep(const KArgs& a, unsigned long long gid, int k, int g, in
   }
 }
 
+// The keep bits of the masked forward AHEAD of the kernel (round 4; the segment plan's four-wave
+// role does the same, njode_mfma_split.h): the forward is ONE chain of thousands of network
+// evaluations per tile, and q4_ode_keep / q4_row_keep -- three hash rounds, up to fifteen serial
+// xorshift words, the bit assembly -- cost ~0.4 us of every one of them although they depend on
+// nothing the chain computes.  k_q4_bits draws them for every (Euler step, tile) and every
+// (observation row, evaluation) in parallel over the chip: the whole lane-group stream of the
+// one-wave kernels, k1 | k2 << 16 (bit q = register q), of which wave w then reads bits
+// 4w .. 4w+3.  Same masks, bit for bit (the sweep never draws masks: it reads the -0.0 marks).
+template <class C>
+__global__ void __launch_bounds__(256) k_q4_bits(KArgs a, int n_tiles) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long long)gridDim.x * 4;
+  const long long n_ode = (long long)a.K * n_tiles;
+  for (long long i = wave; i < n_ode; i += n_waves) {
+    const int k = (int)(i / n_tiles), tile = (int)(i % n_tiles);
+    const int b0i = tile * a.q4_pt + c;
+    const int b = (c < a.q4_pt && b0i < a.B) ? b0i : a.B - 1;
+    const unsigned long long gid = a.gid0 + b;
+    uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1), (uint32_t)k,
+                             NET_ODE);
+    const uint32_t k1 = keep_bits<MF<C>::Q1>(st, a.dc.thr16);
+    const uint32_t k2 = keep_bits<MF<C>::Q1>(st, a.dc.thr16);
+    a.dbits[(size_t)i * 64 + lane] = k1 | (k2 << 16);
+  }
+  // rows: one thread per (row, evaluation, lane group)
+  const long long n_row = (long long)a.n_obs * 12;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_row; i += (long long)gridDim.x * 256) {
+    const int row = (int)(i / 12), e = (int)(i % 12) >> 2, gg = (int)i & 3;
+    const unsigned long long gid = a.gid0 + a.obs_idx[row];
+    const uint32_t tkey = (uint32_t)a.k_jump[a.t_of_row[row]];
+    const uint32_t net = e == 0 ? NET_DEC_BJ : (e == 1 ? NET_ENC : NET_DEC);
+    uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (gg + 1), tkey, net);
+    const uint32_t k1 = keep_bits<16>(st, a.dc.thr16);
+    const uint32_t k2 = keep_bits<16>(st, a.dc.thr16);
+    a.dbits_row[i] = k1 | (k2 << 16);
+  }
+}
+
 // Stored hidden activations of the three evaluations of a jump (readout before = 0, encoder = 1,
 // readout after = 2): per observation row and wave 3 x 2 x 4 registers x 4 lane groups
 constexpr int Q4_JACT_FLOATS = 3 * 2 * 4 * 4;   // = 96 per row and wave
@@ -482,13 +520,20 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
     }
   };
   // readout of the state whose tanh is in image `TH` rows [0, H): this wave's tile of y
+  // (kw: the evaluation's keep bits drawn ahead, k_q4_bits -- used when `ahead`)
+  const bool bits_ahead = DROP && a.dbits_ready != 0;   // (wave-uniform)
+  auto own_bits = [&](uint32_t kw, uint32_t& k1, uint32_t& k2) {
+    k1 = (kw >> (4 * w)) & 15u;
+    k2 = (kw >> (16 + 4 * w)) & 15u;
+  };
   auto readout = [&](lfp TH, const float (&hq)[4], uint32_t tkey, uint32_t net, float (&y)[4], int set,
-                     int row, bool on) {
+                     int row, bool on, uint32_t kw = 0, bool ahead = false) {
     float b0d[DS::Q0], a1l[4], a2l[4];
     q4_input<H, DS::Q0>(TH, b0d, g, c);
     q4_gathered();
     uint32_t k1, k2;
-    q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
+    if (ahead) own_bits(kw, k1, k2);
+    else q4_row_keep<DROP>(a, gid, tkey, net, g, w, k1, k2);
     const f32x4 out = q4_net_fwd_acts<DS, C::ACT, DROP>(Fd, XA, XB, b0d, k1, k2, a.dc.inv_keep, g, c, w,
                                                         a1l, a2l);
     keep_acts(set, row, on, a1l, a2l);
@@ -500,12 +545,14 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
     }
   };
   // encoder of [tanh(xin), mask] staged in EI: this wave's tile of the new state
-  auto encode = [&](const float (&xin)[4], uint32_t tkey, float (&hq)[4], int set, int row, bool on) {
+  auto encode = [&](const float (&xin)[4], uint32_t tkey, float (&hq)[4], int set, int row, bool on,
+                    uint32_t kw = 0, bool ahead = false) {
     float b0e[ES::Q0], a1l[4], a2l[4];
     q4_input<C::ENC_IN, ES::Q0>(EI, b0e, g, c);
     q4_gathered();
     uint32_t k1, k2;
-    q4_row_keep<DROP>(a, gid, tkey, NET_ENC, g, w, k1, k2);
+    if (ahead) own_bits(kw, k1, k2);
+    else q4_row_keep<DROP>(a, gid, tkey, NET_ENC, g, w, k1, k2);
     const f32x4 out = q4_net_fwd_acts<ES, C::ACT, DROP>(Fe, XA, XB, b0e, k1, k2, a.dc.inv_keep, g, c, w,
                                                         a1l, a2l);
     keep_acts(set, row, on, a1l, a2l);
@@ -566,6 +613,9 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
   int i = 0;
   int kj = a.n_times > 0 ? kjump[0] : -1;
   float dt_n = a.K > 0 ? sdt[0] : 0.0f, t_n = a.K > 0 ? stt[0] : 0.0f;
+  const uint32_t* kb_p = bits_ahead ? a.dbits + (size_t)blockIdx.x * 64 + lane : nullptr;
+  const size_t kb_step = (size_t)n_tiles * 64;
+  uint32_t kb_n = (bits_ahead && a.K > 0) ? kb_p[0] : 0u;
   for (int k = 0;; ++k) {
     while (i < a.n_times && kj == k) {
       kj = i + 1 < a.n_times ? kjump[i + 1] : -1;
@@ -586,6 +636,11 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
           xraw[r] = a.X[(size_t)r_ * D + u];
           mraw[r] = C::MASKED ? a.M[(size_t)r_ * D + u] : 1.0f;
         }
+        uint32_t kwj[3] = {0u, 0u, 0u};
+        if (bits_ahead) {
+#pragma unroll
+          for (int e = 0; e < 3; ++e) kwj[e] = a.dbits_row[((size_t)r_ * 3 + e) * 4 + g];
+        }
         // ... and so is the path's next row (its time index is loaded at the commit below)
         const int cn = cur + 1;
         const int cc = cn < a.n_obs ? cn : 0;
@@ -597,7 +652,7 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
             *dst = h[r];
           }
         }
-        readout(IN, h, (uint32_t)k, NET_DEC_BJ, ybj, 0, r_, has);
+        readout(IN, h, (uint32_t)k, NET_DEC_BJ, ybj, 0, r_, has, kwj[0], bits_ahead);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           x[r] = uo[r] < D ? xraw[r] : 0.0f;
@@ -613,12 +668,12 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
         q4_put_n<D>(EI, 0, txin, g, c, w);
         if constexpr (C::MASKED) q4_put_n<D>(EI, D, m, g, c, w);
         block_lds_barrier();
-        encode(xin, (uint32_t)k, hn, 1, r_, has);
+        encode(xin, (uint32_t)k, hn, 1, r_, has, kwj[1], bits_ahead);
 #pragma unroll
         for (int r = 0; r < 4; ++r) thn[r] = tanh_f(hn[r]);
         q4_put_n<H>(HN, 0, thn, g, c, w);
         block_lds_barrier();
-        readout(HN, hn, (uint32_t)k, NET_DEC, yn, 2, r_, has);
+        readout(HN, hn, (uint32_t)k, NET_DEC, yn, 2, r_, has, kwj[2], bits_ahead);
         if (LOSS) {   // compute_loss (models.py:76-110) of this row, reduced over all units
           float sa = 0.0f, sb = 0.0f;
 #pragma unroll
@@ -679,9 +734,11 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
     if (k >= a.K) break;
     {
       const float dt = dt_n, t = t_n;
+      const uint32_t kb = kb_n;
       if (k + 1 < a.K) {
         dt_n = sdt[k + 1];
         t_n = stt[k + 1];
+        if (bits_ahead) kb_n = kb_p[(size_t)(k + 1) * kb_step];
       }
 #ifdef NJ_Q4_STAMP
       const bool q4_on = blockIdx.x == 0 && k == a.K / 2;
@@ -692,7 +749,8 @@ __global__ void __launch_bounds__(256) k_paths_fwd_q4(KArgs a) {
       q4_in0<C>(IN, b0, tau, t - tau, g, c);
       q4_gathered();
       uint32_t k1, k2;
-      q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
+      if (bits_ahead) own_bits(kb, k1, k2);
+      else q4_ode_keep<C, DROP>(a, gid, k, g, w, k1, k2);
       float a1l[4], a2l[4];
       const f32x4 out = q4_net_fwd_acts<OS, C::ACT, DROP>(Fo, XA, XB, b0, k1, k2, a.dc.inv_keep, g, c, w,
                                                           a1l, a2l);

@@ -742,231 +742,6 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
 }
 
 
-// ---- round 4: the four-wave backward as a DELTA sweep + a weight-gradient pass ---------------
-// The four-wave role exists for latency: it walks the longest items, whose chain of Euler steps
-// is the floor of the kernel (and, for small batches, the whole step).  In ode3_bwd_split the 24
-// weight-gradient MFMAs per wave and step (768 cycles), their operand images, two of the three
-// block barriers and the wave-level LDS syncs all sit ON that chain, although nothing on the
-// chain depends on them.  Here the sweep computes the deltas only -- 20 MFMAs per wave and step,
-// ONE exchange image (delta2), two barriers -- and stores them as a record of the activations'
-// shape (StepRec: d2 in a2's place, d3 in h's, d1 in a1's; KArgs::dact).  When the block has
-// swept its tiles, its four waves sum the weight gradients of those tiles from the two records
-// in the bulk role's form (ode3_dw_tiles: wave w takes the steps s = w mod 4 of every tile, 96
-// MFMAs per tile-step, nothing sequential), and flush like the bulk role.
-template <class C> struct OdeBwdDeltaLds { static constexpr int FLOATS = XFLOATS + 4 * MF<C>::QH * 64; };
-
-template <class C, bool DROP>
-NJ_DEV void ode3_bwd_split_delta(const KArgs& a, lfp lds_raw, int worker, int n_workers, int tile0, int tile1) {
-  using M = MF<C>;
-  lfp X2 = lds_raw, PR = X2 + XFLOATS;
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < XFLOATS + 4 * M::QH * 64; i += 256) lds_raw[i] = 0.0f;
-  SplitFragsT<C> F;
-  F.load(a.frag, w, lane);
-  __syncthreads();
-
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  float* const trash = a.trash + lane * C::H;
-  const float ik = DROP ? a.dc.inv_keep : 1.0f;
-  const int n_tiles = tile1 - tile0;
-  for (int round = 0; round * n_workers < n_tiles; ++round) {
-    const int rel = snake_tile(round, worker, n_workers);
-    if (rel >= n_tiles) continue;
-    const int tile = tile0 + rel;
-    const int j = tile * 16 + c;
-    const bool valid = j < a.n_obs;
-    Item<C> it;
-    it.template load<false>(a, j, valid);
-    float lam[M::QH];
-#pragma unroll
-    for (int q = 0; q < M::QH; ++q) {
-      const int u = 4 * q + g;
-      const float v = a.lam_end[(size_t)it.r * C::H + (u < C::H ? u : 0)];
-      lam[q] = (valid && u < C::H) ? v : 0.0f;
-    }
-    const int nmax = uniform(wave_max(it.n));
-    // The records are loaded TWO steps ahead (a step of this sweep is about as long as a trip to
-    // HBM) into two register sets that alternate by the step's parity: a set is refilled, in
-    // place, right after it was unpacked -- no copies, and the wait on a set is two steps old.
-    struct Ahead {
-      SplitRecRaw<C> rec;
-      float dt;
-      long long b16;     // the record's base: also where this step's deltas go
-    };
-    Ahead P0, P1;
-    P0.rec.zero(); P1.rec.zero();
-    P0.dt = P1.dt = 0.0f;
-    P0.b16 = P1.b16 = 0;
-    auto fetch = [&](Ahead& p, int s) {
-      const int sc = s > 0 ? s : 0;                    // (below 0: reload step 0, unused)
-      const int kk = sc < it.n ? it.kbeg + sc : 0;
-      p.b16 = sload_ll(a.base16_s, sc);
-      p.rec.load(rec_block<C>(a.act, p.b16, tile), lane, w);
-      p.dt = a.step_dt[kk];
-    };
-    auto body = [&](Ahead& p, int s) {
-      float h[M::QH], a1u[4], a2u[4];
-      p.rec.unpack(w, a1u, a2u, h);
-      const float dt = s < it.n ? p.dt : 0.0f;
-      const long long b16_cur = p.b16;
-      fetch(p, s - 2);
-      // ---- layer 3: delta3 = dt * lam; W3^T delta3 for the own units
-      float d3[M::QH];
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
-      f32x4 acc = z;
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) acc = mfma4(F.B3[q], d3[q], acc);
-      float d2l[4], d1l[4];
-      split_delta_stored<C, DROP>(acc, a2u, d2l, ik, g, w);
-      split_put(X2, d2l, g, c, w);
-      block_lds_barrier();                             // (a) d2 of all four tiles is in X2
-      // ---- layer 2: W2^T delta2 for the own units
-      float d2[M::QW];
-      split_get<M::QW>(X2, d2, g, c);
-      __builtin_amdgcn_sched_barrier(0);   // (the gather as one batch, as in split_hidden_layers)
-      f32x4 acc0 = z, acc1 = z;
-#pragma unroll
-      for (int q = 0; q < M::QW; q += 2) {
-        acc0 = mfma4(F.B2[q], d2[q], acc0);
-        if (q + 1 < M::QW) acc1 = mfma4(F.B2[q + 1], d2[q + 1], acc1);
-      }
-      acc = acc0 + acc1;
-      split_delta_stored<C, DROP>(acc, a1u, d1l, ik, g, w);
-      // ---- layer 1: W1^T delta1 split over the own k-steps
-      f32x4 part = z;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * w + r < M::QW) part = mfma4(F.B1[r], d1l[r], part);
-      // the deltas of this step, for the weight-gradient pass (behind the chain's own work)
-      split_rec_store<C>(rec_block<C>(a.dact, b16_cur, tile), a.trash, lane, w, d1l, d2l, d3);
-      float gh[M::QH];
-      split_reduce<M::QH>(PR, part, gh, lane, w);      // (b)
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) {
-        const float th = tanh_f(h[q]);
-        const float dth = (4 * q + g) < C::H ? 1.0f - th * th : 0.0f;
-        lam[q] = fmaf(gh[q], dth, lam[q]);
-      }
-    };
-    if (nmax > 0) {
-      fetch(P0, nmax - 1);
-      fetch(P1, nmax - 2);
-    }
-    vm_drain();
-    for (int s = nmax - 1; s >= 0;) {
-      body(P0, s);
-      s -= 1;
-      if (s < 0) break;
-      body(P1, s);
-      s -= 1;
-    }
-    if (w == 0) {
-      float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) {
-        const int u = 4 * q + g;
-        float* dst = u < C::H ? out + u : trash;
-        *dst = lam[q];
-      }
-    }
-  }
-}
-
-// The weight gradients of the tiles [tile0, tile1) block `worker` of `n_workers` swept, from the
-// stored activations (a.act) and deltas (a.dact): wave wv of the block takes the Euler steps
-// s = wv (mod 4) of each tile.  Bulk-role form (ode3_bwd_single): wave-private [unit][chain]
-// images, dW = sum over chains on the matrix cores, tiles G3 / G2 / G1 of the whole network per
-// wave.  Steps are independent: the next step's two records are loaded while this one's 96 MFMAs
-// run.
-template <class C, bool DROP>
-NJ_DEV void ode3_dw_tiles(const KArgs& a, lfp lds_raw, int worker, int n_workers, int tile0, int tile1,
-                          f32x4 (&G3)[MF<C>::MTH][(MF<C>::W + 1 + 15) / 16],
-                          f32x4 (&G2)[MF<C>::MT1][(MF<C>::W + 1 + 15) / 16],
-                          f32x4 (&G1)[MF<C>::MT1][(MF<C>::IN0 + 1 + 15) / 16]) {
-  using M = MF<C>;
-  constexpr int NT1 = (M::W + 1 + 15) / 16, NT0 = (M::IN0 + 1 + 15) / 16;
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int wv = uniform(threadIdx.x >> 6);
-  lfp img_d = lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
-  In0Const<C> K0;
-  K0.init(g);
-  const int n_tiles = tile1 - tile0;
-  for (int round = 0; round * n_workers < n_tiles; ++round) {
-    const int rel = snake_tile(round, worker, n_workers);
-    if (rel >= n_tiles) continue;
-    const int tile = tile0 + rel;
-    const int j = tile * 16 + c;
-    const bool valid = j < a.n_obs;
-    Item<C> it;
-    it.template load<false>(a, j, valid);
-    const int nmax = uniform(wave_max(it.n));
-    // two register sets: while one step's 96 MFMAs run, the records of the wave's next TWO
-    // steps are in flight (a set is refilled, in place, as soon as its last register went into
-    // an image: the loads are consumed two bodies later -- no copies, no young waits)
-    struct Raw {
-      float h[M::QH], a1[M::Q1], a2[M::Q1], d3[M::QH], d1[M::Q1], d2[M::Q1], t;
-    };
-    Raw R0, R1;
-    auto clear = [&](Raw& r) {
-#pragma unroll
-      for (int q = 0; q < M::QH; ++q) { r.h[q] = 0.0f; r.d3[q] = 0.0f; }
-#pragma unroll
-      for (int q = 0; q < M::Q1; ++q) { r.a1[q] = r.a2[q] = r.d1[q] = r.d2[q] = 0.0f; }
-      r.t = 0.0f;
-    };
-    clear(R0);
-    clear(R1);
-    auto fetch = [&](Raw& r, int s) {
-      const int sc = s < nmax ? s : nmax - 1;          // (past the end: reload the last step, unused)
-      const long long b16 = sload_ll(a.base16_s, sc);
-      const float* ba = rec_block<C>(a.act, b16, tile);
-      const float* bd = rec_block<C>(a.dact, b16, tile);
-      r.t = a.step_t[sc < it.n ? it.kbeg + sc : 0];
-      rec_load_A<C>(ba, lane, r.a2, r.h);
-      rec_load_A<C>(bd, lane, r.d2, r.d3);
-      rec_load_B<C>(ba, lane, r.a1);
-      rec_load_B<C>(bd, lane, r.d1);
-    };
-    auto body = [&](Raw& r, int s) {
-      float b0[M::Q0];
-      in0_fill_c<C, 0>(b0, r.h, it.tx, it.tau, r.t - it.tau, g, K0);
-      // layer 3
-      img_write<M::QH>(img_d, r.d3, g, c);
-      img_write<M::Q1>(img_a, r.a2, g, c);
-      wave_lds_sync();
-      dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
-      wave_lds_sync();
-      // layer 2 (a delta record holds Q1 registers; those of the bias / padding units are 0)
-      img_write<M::Q1>(img_d, r.d2, g, c);
-      img_write<M::Q1>(img_a, r.a1, g, c);
-      wave_lds_sync();
-      dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
-      wave_lds_sync();
-      // layer 1
-      img_write<M::Q1>(img_d, r.d1, g, c);
-      img_write<M::Q0>(img_a, b0, g, c);
-      fetch(r, s + 8);                                 // this set's next step
-      wave_lds_sync();
-      dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
-      wave_lds_sync();
-    };
-    if (nmax > 0) {
-      fetch(R0, wv);
-      fetch(R1, wv + 4);
-    }
-    vm_drain();
-    for (int s = wv; s < nmax;) {
-      body(R0, s);
-      s += 4;
-      if (s >= nmax) break;
-      body(R1, s);
-      s += 4;
-    }
-  }
-}
-
 // ---- kernels ------------------------------------------------------------------------------
 // Pure split form (tails; plans too small to mix)
 template <class C, bool DROP, bool TAIL>
@@ -1002,42 +777,19 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
   }
 }
 template <class C> struct OdeBwdMixedLds {
-  static constexpr int A = OdeBwdActLds<C>::FLOATS, B = OdeBwdDeltaLds<C>::FLOATS, D = OdeBwdSplitLds<C>::FLOATS;
-  static constexpr int FLOATS = A > B ? (A > D ? A : D) : (B > D ? B : D);
+  static constexpr int A = OdeBwdActLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;
+  static constexpr int FLOATS = A > B ? A : B;
 };
 // one slab row per block
 template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdMixedLds<C>::FLOATS];
-  using M = MF<C>;
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_blocks;
   const int T = (int)a.base_s[a.K + 1];
-  // both roles read the forward's stored activations (njode_ode2.h): the mixed kernels only
-  // run with a saved forward, which always has them
-  if ((int)blockIdx.x < ns && !a.bwd_delta) {
-    ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);   // (A/B: NJODE_BWD_DELTA=0)
-  } else if ((int)blockIdx.x < ns) {
-    // four-wave role: delta sweep of the block's tiles, then their weight gradients
-    ode3_bwd_split_delta<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
-    __syncthreads();     // every wave's delta records are written (and visible) before any is read
-    constexpr int NT1 = (M::W + 1 + 15) / 16, NT0 = (M::IN0 + 1 + 15) / 16;
-    f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < M::MTH; ++i)
-#pragma unroll
-      for (int n = 0; n < NT1; ++n) G3[i][n] = zero4;
-#pragma unroll
-    for (int i = 0; i < M::MT1; ++i) {
-#pragma unroll
-      for (int n = 0; n < NT1; ++n) G2[i][n] = zero4;
-#pragma unroll
-      for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
-    }
-    for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
-    __syncthreads();
-    ode3_dw_tiles<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, G3, G2, G1);
-    ode3_flush<C, DROP>(a, (lfp)lds_raw, G3, G2, G1, blockIdx.x);
+  // both roles read the forward's step records (njode_ode2.h): the mixed kernels only run with
+  // a saved forward, which always has them
+  if ((int)blockIdx.x < ns) {
+    ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
   } else {
     const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
     ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
