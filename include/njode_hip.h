@@ -98,6 +98,13 @@ typedef struct NjodeDims {
                                    built ahead of time by njode_plan_f32 (below)              */
 #define NJODE_C_NEED_HT 0x100    /* (njode_plan_f32) the forward will be asked for hT         */
 #define NJODE_C_SCHED_TAIL 0x40  /* (with SCHED_KNOWN) k_jump[n_times-1] < n_steps             */
+#define NJODE_C_ROWS_IN_FWD 0x400 /* (with SAVE_BWD, segment plan on the matrix cores) the forward runs the
+                                   backward's pass over the observation rows itself -- both readouts of
+                                   every row, the loss terms AND their adjoints -- instead of a
+                                   forward-only pass; njode_backward_f32 of this call then skips it.
+                                   For callers whose saving forward is always followed by its backward
+                                   (an autograd bridge): the readouts are evaluated once, not twice.
+                                   Same value to the forward and its backward.                        */
 #define NJODE_C_GEN_LOCKSTEP 0x200 /* shape-generic kernels: keep an unmasked loss call on the lockstep
                                    plan (A/B runs, tests).  A CALL flag -- the same value must be
                                    given to njode_plan_f32, the forward and its backward, which lay

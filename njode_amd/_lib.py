@@ -20,6 +20,7 @@ F_MASKED, F_INPUT_CURRENT_T, F_RESIDUAL, F_LOSS_EASY, F_USE_RNN = 0x1, 0x2, 0x4,
 C_TRAIN, C_GET_LOSS, C_RETURN_PATH, C_SAVE_BWD, C_LOSS_IN_BWD = 0x1, 0x2, 0x4, 0x8, 0x10
 C_SCHED_KNOWN, C_SCHED_TAIL = 0x20, 0x40
 C_PLAN_READY, C_NEED_HT = 0x80, 0x100
+C_ROWS_IN_FWD = 0x400       # saving forward also runs the backward's row pass (autograd bridge)
 C_GEN_LOCKSTEP = 0x200      # shape-generic kernels: unmasked loss calls stay on the lockstep plan
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',

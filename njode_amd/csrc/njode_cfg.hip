@@ -139,13 +139,17 @@ template <class CC, bool DROP> static void launch_ode_bwd_mfma(const KArgs& a, b
     k_ode_bwd_mfma<CC, DROP><<<a.n_waves_ode / 4, 256, 0, st>>>(a);
   }
 }
+template <class CC, bool DROP> static void launch_jump_rows_bwd(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_MFMA) {
+    ProfScope ps("k_jump_rows_bwd_mfma", st);
+    k_jump_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
+  }
+}
 template <class CC, bool DROP>
 static void launch_mfma_rows_bwd(const KArgs& a, bool split, hipStream_t st) {
   if constexpr (HAS_MFMA) {
-    {
-      ProfScope ps("k_jump_rows_bwd_mfma", st);
-      k_jump_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
-    }
+    // (defer_loss == 2, NJODE_C_ROWS_IN_FWD: the forward call already ran this pass)
+    if (a.defer_loss != 2) launch_jump_rows_bwd<CC, DROP>(a, st);
     launch_ode_bwd_mfma<CC, DROP>(a, split, st);
     {
       ProfScope ps("k_encode_rows_bwd_mfma", st);
@@ -216,21 +220,47 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       (void)hipEventRecord(side->e1, s2);
       (void)hipStreamWaitEvent(st, side->e1, 0);
     }
+    // the tails (hT: every path from its last observation to the end) need the encoder's outputs
+    // and nothing else of this call: with helper streams they start TOGETHER with the items' ODE
+    // forward, on a stream of their own, and share the chip with it
+    const bool tails_side = tails && side != nullptr;
+    if (tails_side) {
+      // the tails' stream waits for the encoder rows and for the plan's tail order: the latter is
+      // on that stream itself (njode_api.hip, build_plan) or, failing that, on `st` -- then e0,
+      // which the helper stream consumed above, is recorded again here to stand for "everything
+      // `st` has enqueued by now"
+      (void)hipStreamWaitEvent(side->st2, side->e1, 0);
+      if (!side->tails_sorted_on_st2) {
+        (void)hipEventRecord(side->e0, st);
+        (void)hipStreamWaitEvent(side->st2, side->e0, 0);
+      }
+    }
     {   // (the names are the launched kernels', as rocprofv3 lists them)
       ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_mixed" : "k_ode_fwd_mfma")
                                    : "k_ode_fwd_items", st);
       launch_ode_fwd<DROP, false, ODE>(ab, st);
     }
-    if (tails) {
+    if (tails_side) {
+      // (queued behind the forward's launch only so that the items' kernel is dispatched first)
+      ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_split.tails" : "k_ode_fwd_mfma.tails")
+                                   : "k_ode_fwd_items.tails", side->st2);
+      launch_ode_fwd<DROP, true, ODE>(a, side->st2);
+      (void)hipEventRecord(side->e2, side->st2);
+    } else if (tails) {
       ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_split.tails" : "k_ode_fwd_mfma.tails")
                                    : "k_ode_fwd_items.tails", st);
       launch_ode_fwd<DROP, true, ODE>(a, st);
     }
-    if (!(ODE == ODE_MFMA && a.defer_loss)) {
+    if (ODE == ODE_MFMA && a.defer_loss == 2) {
+      // NJODE_C_ROWS_IN_FWD: the backward's row pass here (loss terms, readout gradients, adjoints
+      // at the segment ends) instead of the forward-only pass
+      launch_jump_rows_bwd<C, DROP>(a, st);
+    } else if (!(ODE == ODE_MFMA && a.defer_loss)) {
       ProfScope ps(ODE == ODE_MFMA ? "k_jump_rows_mfma" : "k_jump_rows", st);
       if constexpr (ODE == ODE_MFMA) launch_mfma_jump<C, DROP>(a, st);
       else k_jump_rows<C, DROP><<<cdiv(a.n_obs, 64), 64, 0, st>>>(a);
     }
+    if (tails_side) (void)hipStreamWaitEvent(st, side->e2, 0);
     return hipGetLastError();
   }
 }

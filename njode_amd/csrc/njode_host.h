@@ -47,9 +47,16 @@ struct CfgOps {
 // stream -- the plan is the longer chain, so it stays where no cross-stream hop delays it.
 // e0: recorded on the caller's stream once t_of_row exists (and everything before the call is
 // done); e1: recorded on the helper stream after the encoder rows.
+// st2 / e2 (round 4): a second helper stream of NORMAL priority for the tail items (hT: every path
+// from its last observation to the end of the schedule).  They only need the encoder's outputs, so
+// they start together with the ODE forward of the items and share the chip with it, instead of
+// queueing behind it on the critical path of a training step that never reads hT.
 struct SideInfo {
   hipStream_t st;
   hipEvent_t e0, e1;
+  hipStream_t st2;
+  hipEvent_t e2;
+  int tails_sorted_on_st2;   // the plan's tail order was enqueued on st2 (else on the caller's stream)
 };
 
 // Optional per-kernel timing (njode_profile_enable / njode_profile_read): HIP events

@@ -133,7 +133,8 @@ struct KArgs {
   int loss_easy;
   int want_path, want_loss;  // lockstep plan: return_path / get_loss (wave-uniform)
   int save_traj;             // checkpoint states for the backward pass
-  int defer_loss;            // segment plan: the backward's row kernel writes the loss terms
+  int defer_loss;            // segment plan: the backward's row kernel writes the loss terms (1: it runs in
+                             // the backward call -- fused step; 2: in the forward call, NJODE_C_ROWS_IN_FWD)
   int ode_split;             // segment plan: ODE kernels with four waves per tile (njode_mfma_split.h)
   // ... mixed kernels: the first n_split_* blocks run the longest tiles four waves per tile,
   // the other blocks one wave per tile (njode_mfma_split.h); grid sizes

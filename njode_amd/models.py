@@ -495,7 +495,7 @@ class NJODE(torch.nn.Module):
 
     def _make_call(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
                    return_path, get_loss, until_T, M, save_bwd, plan_key=None, plan_only=False,
-                   want_hT=True, plan=None):
+                   want_hT=True, plan=None, rows_in_fwd=False):
         """``plan_key`` = the caller's original ``(obs_idx, time_ptr)`` objects (looked up among
         the prefetched plans by identity); ``plan`` = a handle returned by ``prefetch_plan``."""
         L = _lib.lib()
@@ -547,6 +547,10 @@ class NJODE(torch.nn.Module):
         flags = ((_lib.C_TRAIN if self.training else 0) | (_lib.C_GET_LOSS if get_loss else 0)
                  | (_lib.C_RETURN_PATH if return_path else 0)
                  | (_lib.C_SAVE_BWD if save_bwd else 0)
+                 # autograd route: the saving forward is followed by its backward, so the forward
+                 # runs the backward's pass over the observation rows itself (the readouts are
+                 # evaluated once instead of twice); carried to the backward by the flags
+                 | (_lib.C_ROWS_IN_FWD if (rows_in_fwd and save_bwd) else 0)
                  # the plan decision travels with the call: the backward never re-reads the
                  # pinned schedule buffer, which the ring may have handed to a later forward
                  | _lib.C_SCHED_KNOWN | (_lib.C_SCHED_TAIL if sched.has_tail() else 0)
@@ -697,7 +701,7 @@ class NJODE(torch.nn.Module):
         if plan in self._plans:
             self._plans.remove(plan)
         plan.taken = True
-        want = flags & ~(_lib.C_LOSS_IN_BWD | _lib.C_PLAN_READY)
+        want = flags & ~(_lib.C_LOSS_IN_BWD | _lib.C_PLAN_READY | _lib.C_ROWS_IN_FWD)
         ok = (plan.sizes == sizes and (plan.flags & ~_lib.C_NEED_HT) == want
               and getattr(plan.obs_idx, '_version', 0) == plan.obs_version
               and (not want_hT or self.masked or (plan.flags & _lib.C_NEED_HT)))
@@ -718,7 +722,7 @@ class NJODE(torch.nn.Module):
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, return_path,
             get_loss, until_T, M, save_bwd=want_grad,
-            plan_key=(obs_idx, time_ptr), want_hT=True, plan=plan)
+            plan_key=(obs_idx, time_ptr), want_hT=True, plan=plan, rows_in_fwd=True)
         dev = start_X.device
         hT = torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
         loss = torch.zeros(1, dtype=torch.float32, device=dev) if get_loss else None

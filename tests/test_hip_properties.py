@@ -35,6 +35,32 @@ def test_two_plans_agree_at_full_size(big):
     np.testing.assert_allclose(hT_s.cpu().numpy(), hT_l.cpu().numpy(), atol=1e-5, rtol=1e-4)
 
 
+def test_autograd_route_equals_the_fused_step_at_full_size(big):
+    """The literal reference sequence -- hT, loss = model(...); loss.backward() -- against
+    loss_and_grad at 20 000 paths, where the call has helper streams: the forward runs the
+    backward's row pass itself (NJODE_C_ROWS_IN_FWD), the tail order and the tails (hT) run on a
+    stream of their own beside the ODE forward.  Same loss, same gradient, and the hT of the
+    lockstep plan."""
+    b, meta, m = big
+    m.train()                     # dropout_rate = 0 here
+    try:
+        args = _args(b, meta)
+        _, loss_f = m.loss_and_grad(*args)
+        g_f = m.flat_grad().clone()
+        m.zero_grad()
+        for _ in range(2):        # (twice: helper-stream events are reused from call to call)
+            hT, loss = m(*args, return_path=False, get_loss=True)
+            loss.backward()
+        g_a = torch.cat([p.grad.reshape(-1) for p in m.parameters()]) / 2.0
+        with torch.no_grad():
+            hT_l = hip_forward(m, b, meta['dt'], meta['maturity'], return_path=True, get_loss=True)[0]
+    finally:
+        m.eval()
+    assert float(loss) == pytest.approx(float(loss_f), rel=1e-6)
+    assert rel_l2(g_a.cpu().numpy(), g_f.cpu().numpy()) < 1e-6
+    np.testing.assert_allclose(hT.detach().cpu().numpy(), hT_l.cpu().numpy(), atol=1e-5, rtol=1e-4)
+
+
 def test_permutation_invariance_at_full_size(big):
     b, meta, m = big
     perm = np.random.RandomState(0).permutation(20000)
