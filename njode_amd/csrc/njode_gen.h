@@ -67,6 +67,7 @@ struct GArgs {
   int D, H, DO, IN0;
   int masked, curt, enc_case, enc_mult, dec_case, dec_mult, loss_easy;
   int B, T, n_obs, K, n_times;
+  int PT;                // lockstep kernels: paths per tile of 16 chains (njode_gen.hip, gen_paths_per_tile)
   const float* start_X;
   const float* X;
   const float* M;
@@ -525,7 +526,9 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
   GLds S;
   S.carve((lfp)smem, a);
   const int tid = threadIdx.x, nth = blockDim.x;
-  const int tile = blockIdx.x, b0 = tile * 16;
+  // (round 4: a tile holds a.PT <= 16 paths, the other chains idle -- see gen_paths_per_tile)
+  const int tile = blockIdx.x, b0 = tile * a.PT;
+  const int nv = a.B - b0 < a.PT ? a.B - b0 : a.PT;           // paths of this tile
   {
     const int n = gen_lds_floats(a.img_rows, a.D, a.H, a.DO);
     for (int e = tid; e < n; e += nth) ((lfp)smem)[e] = 0.0f;
@@ -533,16 +536,16 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
   __syncthreads();
   lfp tau = S.misc, lossacc = S.misc + 16, scale = S.misc + 32;
   const int cch = tid & 15;                                  // chain of this lane in epilogues
-  const int bch = b0 + cch < a.B ? b0 + cch : a.B - 1;
+  const int bch = cch < nv ? b0 + cch : a.B - 1;
   const unsigned long long gidc = a.gid0 + (unsigned long long)bch;
   if (tid < 16) {
     const int b = b0 + tid;
-    scale[tid] = (b < a.B && a.want_loss) ? a.inv_batch / (float)a.n_obs_ot[b] : 0.0f;
+    scale[tid] = (tid < nv && a.want_loss) ? a.inv_batch / (float)a.n_obs_ot[b] : 0.0f;
   }
   // ---- h = encoder(start_X) with a zero mask (models.py:411-414)
   for (int e = tid; e < a.D * 16; e += nth) {
     const int q = e >> 4, c = e & 15, b = b0 + c;
-    const float v = b < a.B ? a.start_X[(size_t)b * a.D + q] : 0.0f;
+    const float v = c < nv ? a.start_X[(size_t)b * a.D + q] : 0.0f;
     S.xr[e] = v;
     S.tx[e] = tanh_acc(v);
     S.mk[e] = 0.0f;
@@ -573,7 +576,6 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
   };
   auto write_row = [&]() {
     if (!a.want_path) return;
-    const int nv = a.B - b0 < 16 ? a.B - b0 : 16;
     float* ph = a.path_h + ((size_t)prow * a.B + b0) * a.H;
     for (int e = tid; e < nv * a.H; e += nth) ph[e] = S.h[(e % a.H) * 16 + e / a.H];
     float* py = a.path_y + ((size_t)prow * a.B + b0) * a.DO;
@@ -588,7 +590,7 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
   int row_pf = -1;
   auto prefetch_rows = [&](int i) {
     if (tid < 16)
-      row_pf = (i < a.n_times && b0 + tid < a.B && a.n_obs > 0) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
+      row_pf = (i < a.n_times && tid < nv && a.n_obs > 0) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
   };
   prefetch_rows(0);
   constexpr int XR = 4;                       // observation values held in registers per thread
@@ -735,11 +737,10 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
     }
   }
   if (a.hT) {
-    const int nv = a.B - b0 < 16 ? a.B - b0 : 16;
     float* ph = a.hT + (size_t)b0 * a.H;
     for (int e = tid; e < nv * a.H; e += nth) ph[e] = S.h[(e % a.H) * 16 + e / a.H];
   }
-  if (a.want_loss && tid < 16 && b0 + tid < a.B) a.loss_terms[b0 + tid] = lossacc[tid];
+  if (a.want_loss && tid < nv) a.loss_terms[b0 + tid] = lossacc[tid];
 }
 
 // =============================================================================================
@@ -750,7 +751,8 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
   GLds S;
   S.carve((lfp)smem, a);
   const int tid = threadIdx.x, nth = blockDim.x;
-  const int tile = blockIdx.x, b0 = tile * 16;
+  const int tile = blockIdx.x, b0 = tile * a.PT;
+  const int nv = a.B - b0 < a.PT ? a.B - b0 : a.PT;           // paths of this tile
   {
     const int n = gen_lds_floats(a.img_rows, a.D, a.H, a.DO);
     for (int e = tid; e < n; e += nth) ((lfp)smem)[e] = 0.0f;
@@ -759,7 +761,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
   lfp scale = S.misc + 32;
   if (tid < 16) {
     const int b = b0 + tid;
-    scale[tid] = b < a.B ? a.inv_batch / (float)a.n_obs_ot[b] : 0.0f;
+    scale[tid] = tid < nv ? a.inv_batch / (float)a.n_obs_ot[b] : 0.0f;
   }
   // adjoints: lam_h = S.h [H], lam_x = S.tx [D] (w.r.t. last_X, masked models)
   lfp lam_h = S.h, lam_x = S.tx, dy = S.y, dybj = S.ybj, lam_hn = S.hn;
@@ -790,7 +792,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
     for (int i = a.jlo[k + 1] - 1; i >= a.jlo[k]; --i) {
       const size_t jrec = (size_t)i * a.T + tile;
       if (!a.flags[jrec]) continue;                           // workgroup-uniform
-      if (tid < 16) S.rows[tid] = (b0 + tid < a.B) ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
+      if (tid < 16) S.rows[tid] = tid < nv ? a.dense[(size_t)i * a.B + b0 + tid] : -1;
       // observation, mask, stored readouts
       {
         const float* yb = a.ybuf + jrec * 2 * a.DO * 16;

@@ -185,7 +185,7 @@ struct Layout {
   size_t sort_tmp_bytes = 0;
   // ... and per-call arrays
   size_t h0row, h0start, h_end, lam_end, g_h0, lam_start;
-  int T;
+  int T, PT = 16;   // path tiles and paths per tile
   int NT = 0;       // item tiles = row tiles
   bool seg = false;
   size_t take(size_t bytes) {
@@ -218,10 +218,34 @@ bool use_seg(const Model& m, int n_obs, int call_flags) {
          !(call_flags & NJODE_C_RETURN_PATH);
 }
 
+// Lockstep plan: paths per tile of 16 chains.  A tile runs the three network evaluations of a jump
+// for all its chains whenever ANY of its paths observes at that time, and a PhysioNet-shaped batch
+// of 50 paths is 4 tiles on a 256-CU chip: fewer paths per tile (the other chains idle) shorten
+// the serial chain of every tile -- same reasoning as q4_paths_per_tile of the specialised masked
+// kernels (njode_api.hip).  The smallest power of two that keeps the tile count within the CUs
+// and the training records (one per Euler step / jump and TILE) within 24 GB.  NJODE_GEN_PT: A/B.
+static int gen_paths_per_tile(const Model& m, int B, int nt, int K, int call_flags) {
+  static const int env = getenv("NJODE_GEN_PT") ? atoi(getenv("NJODE_GEN_PT")) : 0;
+  if (env == 1 || env == 2 || env == 4 || env == 8 || env == 16) return env;
+  int pt = 1;
+  while (pt < 16 && (B + pt - 1) / pt > 256) pt *= 2;
+  if (call_flags & NJODE_C_SAVE_BWD) {
+    auto bytes = [&](int p) {
+      const double T = (double)((B + p - 1) / p);
+      return T * ((double)(K > 0 ? K : 1) * m.a.ode.rec_rows +
+                  (double)(nt > 0 ? nt : 1) * (m.a.enc.rec_rows + 2.0 * m.a.dec.rec_rows)) * 64.0;
+    };
+    while (pt < 16 && bytes(pt) > 24.0e9) pt *= 2;
+  }
+  return pt;
+}
+
 Layout make_layout(const Model& m, int B, int n_obs, int nt, int K, int call_flags) {
   Layout L;
-  L.T = cdiv(B, 16);
   L.seg = use_seg(m, n_obs, call_flags);
+  // (the segment plan's path tiles -- start values, tails -- are tiles of 16)
+  L.PT = L.seg ? 16 : gen_paths_per_tile(m, B, nt, K, call_flags);
+  L.T = cdiv(B, L.PT);
   L.NT = L.seg ? cdiv(n_obs, 16) : 0;
   const size_t T = (size_t)L.T, ntl = (size_t)(nt > 0 ? nt : 1);
   const size_t nr = (size_t)(n_obs > 0 ? n_obs : 1), nb = (size_t)B;
@@ -402,7 +426,7 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
   GArgs& a = c.a;
   a.P = params;
   a.frag = (const float*)(w + c.L.frag);
-  a.B = B; a.T = c.L.T; a.n_obs = n_obs; a.K = K; a.n_times = nt;
+  a.B = B; a.T = c.L.T; a.PT = c.L.PT; a.n_obs = n_obs; a.K = K; a.n_times = nt;
   a.start_X = b->start_X; a.X = b->X; a.M = b->M; a.n_obs_ot = b->n_obs_ot;
   a.inv_batch = 1.0f / b->loss_batch_size;
   a.gid0 = (unsigned long long)b->path_id_offset;

@@ -1,2 +1,4 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -6
-python bench.py > gpurun_out/r4p_bench.json 2> gpurun_out/r4p_bench.err; head -c 400 gpurun_out/r4p_bench.json; echo
+for pt in 1 0; do
+NJODE_GEN_PT=$pt python tools/bench_generic_physio.py 2>/dev/null | sed "s/^/GEN_PT=$pt /" | cut -c1-420
+done
+python tools/bench_generic.py 2>/dev/null > gpurun_out/r04_generic_bench.jsonl; cut -c1-300 gpurun_out/r04_generic_bench.jsonl
