@@ -223,7 +223,7 @@ bool use_seg(const Model& m, int n_obs, int call_flags) {
 // of 50 paths is 4 tiles on a 256-CU chip: fewer paths per tile (the other chains idle) shorten
 // the serial chain of every tile -- same reasoning as q4_paths_per_tile of the specialised masked
 // kernels (njode_api.hip).  The smallest power of two that keeps the tile count within the CUs
-// and the training records (one per Euler step / jump and TILE) within 24 GB.  NJODE_GEN_PT: A/B.
+// and the training records (one per Euler step / jump and TILE) within 40 GB (of the 288).  NJODE_GEN_PT: A/B.
 static int gen_paths_per_tile(const Model& m, int B, int nt, int K, int call_flags) {
   static const int env = getenv("NJODE_GEN_PT") ? atoi(getenv("NJODE_GEN_PT")) : 0;
   if (env == 1 || env == 2 || env == 4 || env == 8 || env == 16) return env;
@@ -235,7 +235,7 @@ static int gen_paths_per_tile(const Model& m, int B, int nt, int K, int call_fla
       return T * ((double)(K > 0 ? K : 1) * m.a.ode.rec_rows +
                   (double)(nt > 0 ? nt : 1) * (m.a.enc.rec_rows + 2.0 * m.a.dec.rec_rows)) * 64.0;
     };
-    while (pt < 16 && bytes(pt) > 24.0e9) pt *= 2;
+    while (pt < 16 && bytes(pt) > 40.0e9) pt *= 2;
   }
   return pt;
 }
