@@ -1,4 +1,3 @@
-for pt in 1 0; do
-NJODE_GEN_PT=$pt python tools/bench_generic_physio.py 2>/dev/null | sed "s/^/GEN_PT=$pt /" | cut -c1-420
-done
-python tools/bench_generic.py 2>/dev/null > gpurun_out/r04_generic_bench.jsonl; cut -c1-300 gpurun_out/r04_generic_bench.jsonl
+python -m pytest tests/test_hip_properties.py tests/test_hip_train_loop.py tests/test_hip_plan_prefetch.py -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests/test_hip_parity.py -x -q -m gpu 2>&1 | tail -3
+python bench.py --no-cpu-baseline --steps 40 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused sums', d['ms_per_step'], d['b100_ms'], d['b200_ms'], 'autograd', d['autograd_route_ms'], d['kernel_ms'])"
