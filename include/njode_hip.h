@@ -56,7 +56,8 @@ typedef struct ihipStream_t* njodeStream_t; /* == hipStream_t */
 #define NJODE_F_LOSS_EASY 0x8        /* which_loss == 'easy'        models.py:109-126 */
 #define NJODE_F_USE_RNN 0x10         /* use_rnn: GRU jump           models.py:202-217 */
 
-#define NJODE_MAX_HIDDEN 4 /* hidden layers per network the library accepts */
+#define NJODE_MAX_HIDDEN 8 /* hidden layers per network the library accepts (round 4: 8, was 4;
+                              the reference's get_ffnn takes any depth, its grids use 1 - 2) */
 
 /* One network of get_ffnn (models.py:140-166): nn_desc = ((width, act), ...). */
 typedef struct NjodeNet {

@@ -37,7 +37,7 @@ EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
 SDE_MODELS = {'BlackScholes': 0, 'OrnsteinUhlenbeck': 1, 'Heston': 2}
 
 
-MAX_HIDDEN = 4
+MAX_HIDDEN = 8      # NJODE_MAX_HIDDEN (include/njode_hip.h)
 
 
 class NjodeNet(C.Structure):

@@ -3,7 +3,7 @@
 // The specialised kernels (njode_mfma*.h, njode_ode2.h) keep a layer's units in registers and
 // a network's A-fragments in VGPRs / LDS, so every model shape is a template instantiation and
 // a layer wider than 63 units does not fit.  This family takes the shape at RUN TIME:
-// any input / hidden / output size, per network any number of hidden layers (<= GEN_MAXL - 1)
+// any input / hidden / output size, per network any number of hidden layers (<= GEN_MAXL - 1 = NJODE_MAX_HIDDEN)
 // of any widths with tanh or relu each, the three networks independent of each other, masked or
 // not, every residual case, dropout.  It serves every shape the build table has no
 // specialisation for (reference grids: widths 80 ... 400, nn_desc = None with hidden_size 50 /
@@ -38,7 +38,7 @@ NJ_DEV f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-constexpr int GEN_MAXL = 5;      // layers per network (<= 4 hidden layers)
+constexpr int GEN_MAXL = NJODE_MAX_HIDDEN + 1;   // layers per network (hidden layers + the output layer)
 constexpr int QU = 4;            // k-steps are padded to a multiple of QU (prefetch depth)
 constexpr uint32_t G_NET_ODE = 0, G_NET_ENC = 1, G_NET_DEC = 2, G_NET_DEC_BJ = 3, G_NET_DEC_ROW = 4;
 constexpr uint32_t G_TKEY_START = 0xffffffffu;

@@ -54,6 +54,9 @@ UNMASKED = {
     # four hidden layers, relu; no residual; one-layer nets
     'deep_relu': (_cfg(1, 12, _w(24, 'relu', 4), _w(24, 'relu', 4), _w(24, 'relu', 4),
                        residual_enc_dec=False), 40),
+    # six hidden layers of three widths, tanh / relu mixed per network (round 4: depth <= 8)
+    'deep6_mixed': (_cfg(1, 10, ((40, 'tanh'), (72, 'relu'), (40, 'tanh'), (24, 'tanh'), (72, 'relu'), (40, 'tanh')),
+                         _w(33, 'tanh', 5), _w(20, 'relu', 8)), 19),
     'one_layer_easy': (_cfg(2, 6, _w(70, 'tanh', 1), _w(18, 'relu', 1), _w(65, 'tanh', 1),
                             which_loss='easy'), 23),
 }

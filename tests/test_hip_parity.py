@@ -289,8 +289,8 @@ def test_unsupported_shape_fails_loudly():
     b, meta = bs_batch(8)
     with pytest.raises(NotImplementedError, match='no gfx950 kernels'):
         hip_forward(m, b, meta['dt'], meta['maturity'])
-    nn5 = tuple((12, 'tanh') for _ in range(5))     # more hidden layers than the library takes
-    m = models.NJODE(1, 10, 1, nn5, nn5, nn5, use_rnn=False, options={}).cuda()
+    nn9 = tuple((12, 'tanh') for _ in range(9))     # more hidden layers than the library takes (8)
+    m = models.NJODE(1, 10, 1, nn9, nn9, nn9, use_rnn=False, options={}).cuda()
     with pytest.raises(NotImplementedError):
         hip_forward(m, b, meta['dt'], meta['maturity'])
 
