@@ -288,10 +288,6 @@ int njode_profile_read(char* out, size_t cap);
 /* Build information: "gfx950;<list of compiled specialisations>". */
 const char* njode_build_info(void);
 
-/* A lowest-priority stream of the current device for building plans ahead (njode_plan_f32 of the
- * NEXT step beside the current one): created on first use, owned by the library, never destroyed.
- * Optional -- any stream of the caller's does. */
-int njode_plan_stream(void** stream);
 
 #ifdef __cplusplus
 }

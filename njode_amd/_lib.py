@@ -27,7 +27,7 @@ EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
            'njode_plan_bytes', 'njode_plan_f32',
            'njode_forward_f32', 'njode_backward_f32', 'njode_backward_loss_f32',
            'njode_adam_step_f32',
-           'njode_last_error', 'njode_build_info', 'njode_plan_stream', 'njode_profile_enable',
+           'njode_last_error', 'njode_build_info', 'njode_profile_enable',
            'njode_profile_read',
            # include/njode_producer.h
            'njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
@@ -129,8 +129,6 @@ def lib():
     L.njode_adam_step_f32.restype = C.c_int
     L.njode_last_error.restype = C.c_char_p
     L.njode_build_info.restype = C.c_char_p
-    L.njode_plan_stream.argtypes = [C.POINTER(C.c_void_p)]
-    L.njode_plan_stream.restype = C.c_int
     L.njode_profile_enable.argtypes = [C.c_int]
     L.njode_profile_enable.restype = C.c_int
     L.njode_profile_read.argtypes = [C.c_char_p, sz]

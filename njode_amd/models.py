@@ -653,13 +653,7 @@ class NJODE(torch.nn.Module):
         if buf is None:
             buf = torch.empty(int(need.value * 1.25) + 4096, dtype=torch.uint8, device=dev)
         if self._plan_stream is None:
-            if os.environ.get('NJODE_PLAN_PRIO') == 'low':     # (A/B: the library's lowest-priority stream)
-                ptr = ctypes.c_void_p()
-                with torch.cuda.device(dev):
-                    _lib.check(L.njode_plan_stream(ctypes.byref(ptr)))
-                self._plan_stream = torch.cuda.ExternalStream(ptr.value, device=dev)
-            else:
-                self._plan_stream = torch.cuda.Stream(device=dev)
+            self._plan_stream = torch.cuda.Stream(device=dev)
         side = self._plan_stream
         side.wait_stream(torch.cuda.current_stream())   # the batch's arrays are ready by now
         with torch.cuda.stream(side):

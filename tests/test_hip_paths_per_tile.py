@@ -1,0 +1,101 @@
+"""Paths per tile of the masked lockstep kernels (round 4).  The specialised kernels
+(njode_mfma_lock4.h, `NJODE_LOCK4_PT`) and the shape-generic ones (njode_gen.h, `NJODE_GEN_PT`)
+take the number of paths a 16-lane tile holds at run time -- 16 / 8 / 4 / 2 / 1, chosen from the
+batch size; the other lanes idle.  The choice is a performance decision only: with dropout ON
+(masks are keyed by the path, not by the tile) a training step must give the same loss, hT and
+gradient whatever it is, up to fp32 summation order, and the keep bits drawn ahead of the forward
+(`NJODE_DROP_BITS_AHEAD=0`: inside it) must be the same bits.  The switches are read once per
+process, so every variant runs in a child process."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from hip_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(TESTS)
+
+_SNIPPET = r'''
+import sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {repo!r})
+import numpy as np, torch
+from njode_amd import models, synthetic_physionet
+NN = (({width}, 'tanh'), ({width}, 'tanh'))
+cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
+           use_rnn=False, bias=True, dropout_rate=0.1, options={{'masked': True, 'device_outputs': True}})
+b = synthetic_physionet.make_batch(batch_size=37, n_grid=60, n_obs_range=(3, 9), seed=3)
+torch.manual_seed(0)
+m = models.NJODE(**cfg).cuda().train()
+m._step_counter = 7
+args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), b['delta_t'], b['T'],
+        b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+hT, loss = m.loss_and_grad(*args, M=b['M'].cuda())
+np.save({out!r}, np.concatenate([[float(loss)], hT.cpu().numpy().reshape(-1).astype(np.float64),
+                                 m.flat_grad().cpu().numpy().astype(np.float64)]))
+'''
+
+
+def _run(tmp_path, tag, width, env_extra):
+    out = str(tmp_path / (tag + '.npy'))
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run([sys.executable, '-c', _SNIPPET.format(tests=TESTS, repo=REPO, out=out, width=width)],
+                       env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize('family,width,var', [('specialised', 50, 'NJODE_LOCK4_PT'), ('generic', 72, 'NJODE_GEN_PT')])
+def test_training_step_does_not_depend_on_the_paths_per_tile(tmp_path, family, width, var):
+    ref = _run(tmp_path, 'pt16', width, {var: '16'})
+    n_h = 37 * 41
+    assert np.isfinite(ref).all() and abs(ref[0]) > 0
+    for pt in ('4', '1', '0'):                      # ('0': the library's own choice)
+        got = _run(tmp_path, 'pt' + pt, width, {var: pt})
+        assert got[0] == pytest.approx(ref[0], rel=2e-5), (family, pt)
+        np.testing.assert_allclose(got[1:1 + n_h], ref[1:1 + n_h], atol=2e-5, rtol=1e-4)
+        assert rel_l2(got[1 + n_h:], ref[1 + n_h:]) < 1e-4, (family, pt)
+
+
+def test_keep_bits_drawn_ahead_are_the_bits_drawn_in_the_kernel(tmp_path):
+    """specialised masked forward: k_q4_bits against q4_ode_keep / q4_row_keep -- the same masks,
+    so the same loss, hT and gradient BIT FOR BIT (one path per tile in both runs)."""
+    a = _run(tmp_path, 'ahead', 50, {'NJODE_LOCK4_PT': '1', 'NJODE_DROP_BITS_AHEAD': '1'})
+    b = _run(tmp_path, 'inside', 50, {'NJODE_LOCK4_PT': '1', 'NJODE_DROP_BITS_AHEAD': '0'})
+    assert np.array_equal(a, b)
+
+
+_SNIPPET_BS = r'''
+import sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {repo!r})
+import numpy as np, torch
+from hip_util import bs_batch, demo_cfg, hip_model
+b, meta = bs_batch(100, seed=11)
+torch.manual_seed(0)
+m = hip_model(demo_cfg(dropout=0.1)).train()
+m._step_counter = 3
+_, loss = m.loss_and_grad(b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'],
+                          meta['maturity'], b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+np.save({out!r}, np.concatenate([[float(loss)], m.flat_grad().cpu().numpy().astype(np.float64)]))
+'''
+
+
+def test_segment_plan_keep_bits_ahead_are_the_bits_of_the_stream(tmp_path):
+    """small plans of the segment plan (every tile four waves wide): the keep bits drawn by the
+    spare blocks of the pack launch (drop_bits_tile_steps) against split_keep_bits inside the
+    kernel: bit-identical loss and gradient at B = 100."""
+    res = {}
+    for tag, val in (('ahead', '1'), ('inside', '0')):
+        out = str(tmp_path / (tag + '_bs.npy'))
+        env = dict(os.environ, NJODE_DROP_BITS_AHEAD=val)
+        p = subprocess.run([sys.executable, '-c', _SNIPPET_BS.format(tests=TESTS, repo=REPO, out=out)],
+                           env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stdout[-3000:]
+        res[tag] = np.load(out)
+    assert np.isfinite(res['ahead']).all() and abs(res['ahead'][0]) > 0
+    assert np.array_equal(res['ahead'], res['inside'])

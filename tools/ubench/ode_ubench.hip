@@ -184,7 +184,7 @@ static Problem make_problem(int n_tiles, int L, bool drop) {
     const long long n16 = (n + 15) / 16 * 16;
     for (int s = 0; s < L + 2; ++s) b16[s] = (long long)s * n16;
     long long* d16 = dalloc<long long>(L + 2); h2d(d16, b16); a.base16_s = d16;
-    a.act = dalloc<float>((size_t)n16 * L * 8 * MF<C>::Q1);
+    a.act = dalloc<float>((size_t)n16 * L * StepRec<C>::PER_CHAIN);   // (round 4: lane-major step records)
   }
   a.K = L;
   a.n_times = 1;
