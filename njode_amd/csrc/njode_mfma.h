@@ -26,6 +26,39 @@ NJ_DEV f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- edge rows (round 4) ------------------------------------------------------------------
+// A layer of W units takes ceil(W / 16) output tiles of 16x16x4; with W % 16 = 1 or 2 (W = 50:
+// units 48, 49) the last tile costs a full tile's 32 cycles per k-step for one or two rows.
+// Those rows go through v_mfma_f32_4x4x1_16b_f32 instead: 16 independent blocks of 4x4x1,
+// 16 cycles (measured: 15 - 18).  With the B operand in D-layout (lane (g, c): unit 4q + g of chain c) block
+// 4g + c / 4 sees input unit 4q + g of chains 4 (c / 4) .. + 3, the A operand of lane (g, c) is
+// W[edge row c % 4][4q + g], and after the Q k-steps register i of lane (g, c) holds the part of
+// out[edge row i][chain c] that runs over the input units = g (mod 4).  edge_reduce adds the four
+// parts of rows 0 and 1 (two lane swaps, two adds): lane groups 0 / 2 get row 0's total, 1 / 3
+// row 1's -- register 0 of the tile in D-layout once the groups >= R are cleared.
+// (tools/ubench/mfma4x4_check.hip checks the layout, the reduction and the issue cost.)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+NJ_DEV f32x4 mfma1(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+NJ_DEV float edge_reduce(float p0, float p1) {
+  const u32x2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+  const float t = __uint_as_float(s[0]) + __uint_as_float(s[1]);
+  const u32x2 w = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return __uint_as_float(w[0]) + __uint_as_float(w[1]);
+}
+template <int W> struct EdgeRows {                 // of a layer with W output units
+  static constexpr int R = (W % 16 == 1 || W % 16 == 2) ? W % 16 : 0;
+  static constexpr int TILE = R ? W / 16 : -1;     // the tile the edge rows stand for
+};
+// the lane whose A-fragment value of the edge tile is this lane's 4x4x1 operand: row c % 4 of the
+// tile is fragment row i with row_unit(mt, i) = 16 mt + i, i.e. i = 4 (c % 4); same lane group
+NJ_DEV int edge_lane(int lane) { return (lane & 48) | ((lane & 3) << 2); }
+template <int R> NJ_DEV f32x4 edge_tile(const f32x4& part, int g) {
+  const float x = edge_reduce(part[0], part[1]);
+  return f32x4{g < R ? x : 0.0f, 0.0f, 0.0f, 0.0f};
+}
+
 // Fragment tables of the ODE network (NH == 2)
 template <class C> struct MF {
   static constexpr int H = C::H, D = C::D, W = C::W, IN0 = C::ODE_IN;
@@ -326,6 +359,37 @@ NJ_DEV void dw_accumulate(lfp img_d, lfp img_a, f32x4 (&G)[MT][NT], int g, int c
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) G[mt][nt] = mfma4(af[mt][s], bf[nt][s], G[mt][nt]);
+}
+// dW of a W x (W + 1) layer with edge rows (ET = W / 16 whole tiles each way): the ET x ET tiles
+// on 16x16x4 as dw_accumulate; the rows u >= 16 ET against EVERY column (GM: register i of lane l
+// = dW[16 ET + i][l]) and the columns v >= 16 ET against the rows (GN: register i of lane l =
+// dW[l][16 ET + i]; its lanes >= 16 ET repeat GM's corner and are not flushed) as 4x4x1 outer
+// products, one chain per instruction: 32 x 16 cycles where the two padded tile strips took
+// (2 ET + 1) x 4 x 32.
+template <int ET>
+NJ_DEV void dw_accumulate_edge(lfp img_d, lfp img_a, f32x4 (&G)[ET][ET], f32x4 (&GM)[2], f32x4 (&GN)[2],
+                               int lane, int g, int c) {
+  f4 af[ET], bf[ET];
+#pragma unroll
+  for (int mt = 0; mt < ET; ++mt) af[mt] = *(lf4p)(img_d + (16 * mt + c) * IMG_STRIDE + 4 * g);
+#pragma unroll
+  for (int nt = 0; nt < ET; ++nt) bf[nt] = *(lf4p)(img_a + (16 * nt + c) * IMG_STRIDE + 4 * g);
+  lf4p dl = (lf4p)(img_d + lane * IMG_STRIDE), al = (lf4p)(img_a + lane * IMG_STRIDE);
+  lf4p de = (lf4p)(img_d + (16 * ET + (lane & 3)) * IMG_STRIDE);
+  lf4p ae = (lf4p)(img_a + (16 * ET + (lane & 3)) * IMG_STRIDE);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const f4 x = de[s], y = al[s], u = ae[s], v = dl[s];
+#pragma unroll
+    for (int mt = 0; mt < ET; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < ET; ++nt) G[mt][nt] = mfma4(af[mt][s], bf[nt][s], G[mt][nt]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      GM[k & 1] = mfma1(x[k], y[k], GM[k & 1]);
+      GN[k & 1] = mfma1(u[k], v[k], GN[k & 1]);
+    }
+  }
 }
 
 // delta of a hidden layer from the transposed product and the saved activation

@@ -16,6 +16,10 @@ template <int IN_, int OUT_, int W_> struct MS {
   static constexpr int NT1 = (W + 1 + 15) / 16, NT0 = (IN + 1 + 15) / 16;
   static constexpr int F1 = 0, F2 = F1 + MT1 * Q0, F3 = F2 + MT1 * Q1, NFWD = F3 + MTO * Q1;
   static constexpr int B3 = NFWD, B2 = B3 + MT1 * QO, B1 = B2 + MT1 * QW, NALL = B1 + MTI * QW;
+  // edge rows of the W-unit layers (njode_mfma.h): tile ET stands for ER rows on 4x4x1; dW2 is
+  // then held as G2M x G2N tiles of 16x16 + two edge accumulators (dw_accumulate_edge)
+  static constexpr int ET = EdgeRows<W>::TILE, ER = EdgeRows<W>::R;
+  static constexpr int G2M = ER ? ET : MT1, G2N = ER ? ET : NT1;
 };
 
 // A-fragments of all six products of one network (inputs in natural order)
@@ -61,10 +65,11 @@ template <class S> struct FwdFrags {
   NJ_DEV void load(const float* frag, int lane) {
 #pragma unroll
     for (int mt = 0; mt < S::MT1; ++mt) {
+      const int l = mt == S::ET ? edge_lane(lane) : lane;   // (edge tile: its rows' 4x4x1 operands)
 #pragma unroll
-      for (int q = 0; q < S::Q0; ++q) A1[mt][q] = frag[(S::F1 + mt * S::Q0 + q) * 64 + lane];
+      for (int q = 0; q < S::Q0; ++q) A1[mt][q] = frag[(S::F1 + mt * S::Q0 + q) * 64 + l];
 #pragma unroll
-      for (int q = 0; q < S::Q1; ++q) A2[mt][q] = frag[(S::F2 + mt * S::Q1 + q) * 64 + lane];
+      for (int q = 0; q < S::Q1; ++q) A2[mt][q] = frag[(S::F2 + mt * S::Q1 + q) * 64 + l];
     }
 #pragma unroll
     for (int mt = 0; mt < S::MTO; ++mt)
@@ -75,11 +80,14 @@ template <class S> struct FwdFrags {
   NJ_DEV float a1(int mt, int q) const { return A1[mt][q]; }
   NJ_DEV float a2(int mt, int q) const { return A2[mt][q]; }
   NJ_DEV float a3(int mt, int q) const { return A3[mt][q]; }
+  NJ_DEV float e1(int q) const { return A1[S::ET < 0 ? 0 : S::ET][q]; }
+  NJ_DEV float e2(int q) const { return A2[S::ET < 0 ? 0 : S::ET][q]; }
 };
 template <class S> struct LdsFrags {
   lfp base;   // this lane's column of the block's fragment image: base[f * 64]
   lfp cur;
-  NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; }
+  int de;     // edge rows: their 4x4x1 operands are the edge tile's vectors at lane + de
+  NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; de = edge_lane(lane) - lane; }
   // copy all S::NALL fragment vectors of the network from global into LDS (whole block)
   static NJ_DEV void stage(lfp img, const float* frag, int tid, int nthreads) {
     for (int i = tid; i < S::NALL * 64; i += nthreads) img[i] = frag[i];
@@ -95,24 +103,31 @@ template <class S> struct LdsFrags {
   NJ_DEV float b3(int mt, int q) const { return cur[(S::B3 + mt * S::QO + q) * 64]; }
   NJ_DEV float b2(int mt, int q) const { return cur[(S::B2 + mt * S::QW + q) * 64]; }
   NJ_DEV float b1(int mt, int q) const { return cur[(S::B1 + mt * S::QW + q) * 64]; }
+  NJ_DEV float e1(int q) const { return cur[(S::F1 + S::ET * S::Q0 + q) * 64 + de]; }
+  NJ_DEV float e2(int q) const { return cur[(S::F2 + S::ET * S::Q1 + q) * 64 + de]; }
+  NJ_DEV float eb3(int q) const { return cur[(S::B3 + S::ET * S::QO + q) * 64 + de]; }
+  NJ_DEV float eb2(int q) const { return cur[(S::B2 + S::ET * S::QW + q) * 64 + de]; }
 };
 template <class S> struct GradTiles {
-  f32x4 G3[S::MTO][S::NT1], G2[S::MT1][S::NT1], G1[S::MT1][S::NT0];
+  f32x4 G3[S::MTO][S::NT1], G2[S::G2M][S::G2N], GM[2], GN[2], G1[S::MT1][S::NT0];
   NJ_DEV void zero() {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    GM[0] = GM[1] = GN[0] = GN[1] = z;
 #pragma unroll
     for (int i = 0; i < S::MTO; ++i)
 #pragma unroll
       for (int n = 0; n < S::NT1; ++n) G3[i][n] = z;
 #pragma unroll
-    for (int i = 0; i < S::MT1; ++i) {
+    for (int i = 0; i < S::G2M; ++i)
 #pragma unroll
-      for (int n = 0; n < S::NT1; ++n) G2[i][n] = z;
+      for (int n = 0; n < S::G2N; ++n) G2[i][n] = z;
+#pragma unroll
+    for (int i = 0; i < S::MT1; ++i) {
 #pragma unroll
       for (int n = 0; n < S::NT0; ++n) G1[i][n] = z;
     }
   }
-  static constexpr int NG = S::MTO * S::NT1 + S::MT1 * S::NT1 + S::MT1 * S::NT0;
+  static constexpr int NG = S::MTO * S::NT1 + S::G2M * S::G2N + (S::ER ? 2 : 0) + S::MT1 * S::NT0;
   template <class F> NJ_DEV void for_tiles(F f) {
     int i = 0;
 #pragma unroll
@@ -120,9 +135,13 @@ template <class S> struct GradTiles {
 #pragma unroll
       for (int nt = 0; nt < S::NT1; ++nt) f(G3[mt][nt], i++);
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt)
+    for (int mt = 0; mt < S::G2M; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < S::NT1; ++nt) f(G2[mt][nt], i++);
+      for (int nt = 0; nt < S::G2N; ++nt) f(G2[mt][nt], i++);
+    if constexpr (S::ER != 0) {
+      f(GM[0], i++);
+      f(GN[0], i++);
+    }
 #pragma unroll
     for (int mt = 0; mt < S::MT1; ++mt)
 #pragma unroll
@@ -133,6 +152,10 @@ template <class S> struct GradTiles {
   // stores ONE slab row.  Returns true for the wave that holds the sum.
   NJ_DEV bool reduce_block(lfp lds, int wv, int lane) {
     f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds;
+    if constexpr (S::ER != 0) {   // (two accumulators each: independent 4x4x1 chains)
+      GM[0] += GM[1];
+      GN[0] += GN[1];
+    }
     __syncthreads();
     if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
     __syncthreads();
@@ -149,17 +172,43 @@ template <class S> struct GradTiles {
     float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
           *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt)
+    for (int mt = 0; mt < S::G2M; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int uo = 16 * mt + 4 * g + r;
         if (uo < S::W) {
 #pragma unroll
-          for (int nt = 0; nt < S::NT1; ++nt) {
+          for (int nt = 0; nt < S::G2N; ++nt) {
             const int ui = 16 * nt + c;
             if (ui < S::W) W2[uo * S::W + ui] = G2[mt][nt][r];
             else if (ui == S::W) b2[uo] = G2[mt][nt][r];
           }
+        }
+      }
+    if constexpr (S::ER != 0) {
+      // GM: register i of lane l = dW2[16 ET + i][l]; GN: = dW2[l][16 ET + i] for l < 16 ET
+      const int lane = 16 * g + c;
+#pragma unroll
+      for (int i = 0; i < S::ER; ++i) {
+        const int uo = 16 * S::ET + i;
+        if (lane < S::W) W2[uo * S::W + lane] = GM[0][i];
+        else if (lane == S::W) b2[uo] = GM[0][i];
+      }
+      if (lane < 16 * S::ET) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ui = 16 * S::ET + i;
+          if (ui < S::W) W2[lane * S::W + ui] = GN[0][i];
+          else if (ui == S::W) b2[lane] = GN[0][i];
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < S::MT1; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int uo = 16 * mt + 4 * g + r;
+        if (uo < S::W) {
 #pragma unroll
           for (int nt = 0; nt < S::NT0; ++nt) {
             const int ui = 16 * nt + c;
@@ -197,14 +246,18 @@ NJ_DEV void mnet_fwd(FP& F, const float (&b0)[S::Q0], float (&a1)[S::Q1],
 #pragma unroll
   for (int q = 0; q < S::Q0; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.a1(mt, q), b0[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt)
+      acc[mt] = mt == S::ET ? mfma1(F.e1(q), b0[q], acc[mt]) : mfma4(F.a1(mt, q), b0[q], acc[mt]);
+  if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
   hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a1, k1, inv_keep, g);
 #pragma unroll
   for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
 #pragma unroll
   for (int q = 0; q < S::Q1; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(F.a2(mt, q), a1[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt)
+      acc[mt] = mt == S::ET ? mfma1(F.e2(q), a1[q], acc[mt]) : mfma4(F.a2(mt, q), a1[q], acc[mt]);
+  if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
   hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a2, k2, inv_keep, g);
 #pragma unroll
   for (int mt = 0; mt < S::MTO; ++mt) out[mt] = z;
@@ -237,20 +290,25 @@ NJ_DEV void mnet_bwd(FP& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
 #pragma unroll
   for (int q = 0; q < S::QO; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.b3(mt, q), dout[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt)
+      acc[mt] = mt == S::ET ? mfma1(Bf.eb3(q), dout[q], acc[mt]) : mfma4(Bf.b3(mt, q), dout[q], acc[mt]);
+  if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
   float d2[S::QW];
   hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a2, d2, k2, inv_keep, keepf);
   wave_lds_sync();
   img_write<S::QW>(img_d, d2, g, c);
   img_write<S::Q1>(img_a, a1, g, c);
   wave_lds_sync();
-  dw_accumulate<S::MT1, S::NT1>(img_d, img_a, G.G2, g, c);
+  if constexpr (S::ER != 0) dw_accumulate_edge<S::G2M>(img_d, img_a, G.G2, G.GM, G.GN, 16 * g + c, g, c);
+  else dw_accumulate<S::G2M, S::G2N>(img_d, img_a, G.G2, g, c);
 #pragma unroll
   for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
 #pragma unroll
   for (int q = 0; q < S::QW; ++q)
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = mfma4(Bf.b2(mt, q), d2[q], acc[mt]);
+    for (int mt = 0; mt < S::MT1; ++mt)
+      acc[mt] = mt == S::ET ? mfma1(Bf.eb2(q), d2[q], acc[mt]) : mfma4(Bf.b2(mt, q), d2[q], acc[mt]);
+  if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
   float d1[S::QW];
   hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a1, d1, k1, inv_keep, keepf);
   wave_lds_sync();

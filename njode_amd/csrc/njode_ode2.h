@@ -318,17 +318,24 @@ NJ_DEV void hidden_pair(const f32x4& t0, const f32x4& t1, float (&av)[MF<C>::Q1]
   if constexpr (QB >= 4 * MT0 && QB < 4 * MT0 + 8) av[QB] = g == GB ? 1.0f : av[QB];
 }
 
-// A x b for the output tiles [MT0, MT0 + 2) over all Q k-steps, two accumulators alternating
-template <int MT, int Q, int MT0>
-NJ_DEV void mfma_pair(const float (&A)[MT][Q], const float (&bv)[Q], f32x4& t0, f32x4& t1) {
+// A x b for the output tiles [MT0, MT0 + 2) over all Q k-steps, two accumulators alternating.
+// ET >= 0: tile ET stands for ER edge rows (njode_mfma.h): A[ET][q] holds their 4x4x1 operands
+template <int MT, int Q, int MT0, int ET = -1, int ER = 0>
+NJ_DEV void mfma_pair(const float (&A)[MT][Q], const float (&bv)[Q], f32x4& t0, f32x4& t1, int g = 0) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   t0 = z;
   t1 = z;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    t0 = mfma4(A[MT0][q], bv[q], t0);
-    if constexpr (MT0 + 1 < MT) t1 = mfma4(A[MT0 + 1][q], bv[q], t1);
+    if constexpr (MT0 == ET) t0 = mfma1(A[MT0][q], bv[q], t0);
+    else t0 = mfma4(A[MT0][q], bv[q], t0);
+    if constexpr (MT0 + 1 < MT) {
+      if constexpr (MT0 + 1 == ET) t1 = mfma1(A[MT0 + 1][q], bv[q], t1);
+      else t1 = mfma4(A[MT0 + 1][q], bv[q], t1);
+    }
   }
+  if constexpr (MT0 == ET) t0 = edge_tile<ER>(t0, g);
+  if constexpr (MT0 + 1 == ET && MT0 + 1 < MT) t1 = edge_tile<ER>(t1, g);
 }
 
 template <class C> struct Ode2FwdFrags {
@@ -337,10 +344,12 @@ template <class C> struct Ode2FwdFrags {
   NJ_DEV void load(const float* frag, int lane) {
 #pragma unroll
     for (int mt = 0; mt < M::MT1; ++mt) {
+      // (the edge tile: the 4x4x1 operands of its rows, taken from the same table)
+      const int l = mt == EdgeRows<M::W>::TILE ? edge_lane(lane) : lane;
 #pragma unroll
-      for (int q = 0; q < M::Q0; ++q) A1[mt][q] = frag[(M::F1 + mt * M::Q0 + q) * 64 + lane];
+      for (int q = 0; q < M::Q0; ++q) A1[mt][q] = frag[(M::F1 + mt * M::Q0 + q) * 64 + l];
 #pragma unroll
-      for (int q = 0; q < M::Q1; ++q) A2[mt][q] = frag[(M::F2 + mt * M::Q1 + q) * 64 + lane];
+      for (int q = 0; q < M::Q1; ++q) A2[mt][q] = frag[(M::F2 + mt * M::Q1 + q) * 64 + l];
     }
 #pragma unroll
     for (int mt = 0; mt < M::MTH; ++mt)
@@ -355,7 +364,7 @@ NJ_DEV void hidden_layer2(const float (&A)[MF<C>::MT1][QIN], const float (&bv)[Q
                           float (&av)[MF<C>::Q1], uint32_t& st, uint32_t thr16, int g) {
   if constexpr (MT0 < MF<C>::MT1) {
     f32x4 t0, t1;
-    mfma_pair<MF<C>::MT1, QIN, MT0>(A, bv, t0, t1);
+    mfma_pair<MF<C>::MT1, QIN, MT0, EdgeRows<MF<C>::W>::TILE, EdgeRows<MF<C>::W>::R>(A, bv, t0, t1, g);
     hidden_pair<C, DROP, MT0>(t0, t1, av, st, thr16, g);
     hidden_layer2<C, DROP, QIN, MT0 + 2>(A, bv, av, st, thr16, g);
   }
@@ -484,6 +493,7 @@ template <class C> struct OdeLdsFragsT {
   static NJ_DEV void stage(lfp img, const float* frag, int tid, int nthreads) {
     for (int i = tid; i < NVEC * 64; i += nthreads) img[i] = frag[M::NFWD * 64 + i];
   }
+  static constexpr int ET = EdgeRows<M::W>::TILE;   // (the W-row products W3^T, W2^T: edge rows)
   NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; }
   NJ_DEV void begin() {
     unsigned v = (unsigned)(unsigned long long)base;
@@ -493,6 +503,9 @@ template <class C> struct OdeLdsFragsT {
   NJ_DEV float b3(int mt, int q) const { return cur[(M::B3 - M::NFWD + mt * M::QH + q) * 64]; }
   NJ_DEV float b2(int mt, int q) const { return cur[(M::B2 - M::NFWD + mt * M::QW + q) * 64]; }
   NJ_DEV float b1(int mt, int q) const { return cur[(M::B1 - M::NFWD + mt * M::QW + q) * 64]; }
+  // 4x4x1 operands of the edge rows: the edge tile's vectors read at lane edge_lane(lane)
+  NJ_DEV float e3(int q, int de) const { return cur[(M::B3 - M::NFWD + ET * M::QH + q) * 64 + de]; }
+  NJ_DEV float e2(int q, int de) const { return cur[(M::B2 - M::NFWD + ET * M::QW + q) * 64 + de]; }
 };
 template <class C> struct OdeBwdActLds {
   using M = MF<C>;
@@ -510,18 +523,30 @@ template <class C> struct OdeBwdActLds {
 #define NJ_BWD_ABL 0
 #endif
 #define BWD_ABL(bit) ((NJ_BWD_ABL) & (bit))
-// flush of a 256-thread block's four workers (the bulk role; the four-wave role's dW pass): their
-// register tiles are summed through LDS in fixed order and stored as ONE slab row
+// tiles of dW2 held as 16x16 accumulators: with edge rows (dw_accumulate_edge) ET x ET + GM, GN
+template <class C> struct OdeG2 {
+  using M = MF<C>;
+  static constexpr int ET = EdgeRows<M::W>::TILE, ER = EdgeRows<M::W>::R;
+  static constexpr int MT = ER ? ET : M::MT1, NT = ER ? ET : (M::W + 1 + 15) / 16;
+  static constexpr int NE = ER ? 4 : 0;            // edge accumulators (GM[2], GN[2])
+};
+// flush of a 256-thread block's four workers (the bulk role): their register tiles are summed
+// through LDS in fixed order and stored as ONE slab row
 template <class C, bool DROP>
 NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<C>::W + 1 + 15) / 16],
-                       f32x4 (&G2)[MF<C>::MT1][(MF<C>::W + 1 + 15) / 16],
+                       f32x4 (&G2)[OdeG2<C>::MT][OdeG2<C>::NT], f32x4 (&GM)[2], f32x4 (&GN)[2],
                        f32x4 (&G1)[MF<C>::MT1][(MF<C>::IN0 + 1 + 15) / 16], int slab_row) {
   using M = MF<C>;
   using NL = typename C::Ode;
+  using E2 = OdeG2<C>;
   constexpr int NT1 = (M::W + 1 + 15) / 16, NT0 = (M::IN0 + 1 + 15) / 16;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  if constexpr (E2::ER != 0) {   // (two accumulators each: independent 4x4x1 chains)
+    GM[0] += GM[1];
+    GN[0] += GN[1];
+  }
   // ---- flush (as ode_bwd_single): one slab row per block
-  constexpr int NG = M::MTH * NT1 + M::MT1 * NT1 + M::MT1 * NT0;
+  constexpr int NG = M::MTH * NT1 + E2::MT * E2::NT + (E2::ER ? 2 : 0) + M::MT1 * NT0;
   static_assert(3 * NG * 64 * 4 <= OdeBwdActLds<C>::FLOATS, "tile reduction does not fit the LDS");
   __syncthreads();
   f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds_raw;
@@ -532,9 +557,13 @@ NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<
 #pragma unroll
       for (int nt = 0; nt < NT1; ++nt) f(G3[mt][nt], i++);
 #pragma unroll
-    for (int mt = 0; mt < M::MT1; ++mt)
+    for (int mt = 0; mt < E2::MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT1; ++nt) f(G2[mt][nt], i++);
+      for (int nt = 0; nt < E2::NT; ++nt) f(G2[mt][nt], i++);
+    if constexpr (E2::ER != 0) {
+      f(GM[0], i++);
+      f(GN[0], i++);
+    }
 #pragma unroll
     for (int mt = 0; mt < M::MT1; ++mt)
 #pragma unroll
@@ -554,17 +583,42 @@ NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<
   float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
         *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
 #pragma unroll
-  for (int mt = 0; mt < M::MT1; ++mt)
+  for (int mt = 0; mt < E2::MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int uo = 16 * mt + 4 * g + r;
       if (uo < M::W) {
 #pragma unroll
-        for (int nt = 0; nt < NT1; ++nt) {
+        for (int nt = 0; nt < E2::NT; ++nt) {
           const int ui = 16 * nt + c;
           if (ui < M::W) W2[uo * M::W + ui] = ik * G2[mt][nt][r];
           else if (ui == M::W) b2[uo] = G2[mt][nt][r];
         }
+      }
+    }
+  if constexpr (E2::ER != 0) {
+    // GM: register i of lane l = dW2[16 ET + i][l]; GN: = dW2[l][16 ET + i] for l < 16 ET
+#pragma unroll
+    for (int i = 0; i < E2::ER; ++i) {
+      const int uo = 16 * E2::ET + i;
+      if (lane < M::W) W2[uo * M::W + lane] = ik * GM[0][i];
+      else if (lane == M::W) b2[uo] = GM[0][i];
+    }
+    if (lane < 16 * E2::ET) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ui = 16 * E2::ET + i;
+        if (ui < M::W) W2[lane * M::W + ui] = ik * GN[0][i];
+        else if (ui == M::W) b2[lane] = GN[0][i];
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < M::MT1; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int uo = 16 * mt + 4 * g + r;
+      if (uo < M::W) {
 #pragma unroll
         for (int nt = 0; nt < NT0; ++nt) {
           const int ui = 16 * nt + c;
@@ -608,16 +662,22 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   In0Const<C> K0;
   K0.init(g);
 
-  f32x4 G3[M::MTH][NT1], G2[M::MT1][NT1], G1[M::MT1][NT0];
+  using E2 = OdeG2<C>;
+  constexpr int ET = E2::ER ? E2::ET : -1, ER = E2::ER;
+  const int de = edge_lane(lane) - lane;          // edge operands: the fragment vector at that lane
+  f32x4 G3[M::MTH][NT1], G2[E2::MT][E2::NT], GM[2], GN[2], G1[M::MT1][NT0];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  GM[0] = GM[1] = GN[0] = GN[1] = zero4;
 #pragma unroll
   for (int i = 0; i < M::MTH; ++i)
 #pragma unroll
     for (int n = 0; n < NT1; ++n) G3[i][n] = zero4;
 #pragma unroll
-  for (int i = 0; i < M::MT1; ++i) {
+  for (int i = 0; i < E2::MT; ++i)
 #pragma unroll
-    for (int n = 0; n < NT1; ++n) G2[i][n] = zero4;
+    for (int n = 0; n < E2::NT; ++n) G2[i][n] = zero4;
+#pragma unroll
+  for (int i = 0; i < M::MT1; ++i) {
 #pragma unroll
     for (int n = 0; n < NT0; ++n) G1[i][n] = zero4;
   }
@@ -687,7 +747,9 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
         for (int q = 0; q < M::QH; ++q)
 #pragma unroll
-          for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
+          for (int mt = 0; mt < M::MT1; ++mt)
+            acc[mt] = mt == ET ? mfma1(F.e3(q, de), d3[q], acc[mt]) : mfma4(F.b3(mt, q), d3[q], acc[mt]);
+        if constexpr (ER != 0) acc[ET] = edge_tile<ER>(acc[ET], g);
       } else {
 #pragma unroll
         for (int mt = 0; mt < M::MT1; ++mt) acc[mt][0] = d3[0];
@@ -705,14 +767,19 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
         img_write<M::Q1>(img_a, a1, g, c);
       }
       if (!BWD_ABL(4)) wave_lds_sync();
-      if (!BWD_ABL(1)) dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
+      if (!BWD_ABL(1)) {
+        if constexpr (ER != 0) dw_accumulate_edge<E2::MT>(img_d, img_a, G2, GM, GN, lane, g, c);
+        else dw_accumulate<E2::MT, E2::NT>(img_d, img_a, G2, g, c);
+      }
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
       if (!BWD_ABL(2)) {
 #pragma unroll
         for (int q = 0; q < M::QW; ++q)
 #pragma unroll
-          for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
+          for (int mt = 0; mt < M::MT1; ++mt)
+            acc[mt] = mt == ET ? mfma1(F.e2(q, de), d2[q], acc[mt]) : mfma4(F.b2(mt, q), d2[q], acc[mt]);
+        if constexpr (ER != 0) acc[ET] = edge_tile<ER>(acc[ET], g);
       } else {
 #pragma unroll
         for (int mt = 0; mt < M::MT1; ++mt) acc[mt][0] = d2[mt];
@@ -765,7 +832,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   }
 
   if (BWD_ABL(128)) return;
-  ode3_flush<C, DROP>(a, lds_raw, G3, G2, G1, slab_row);
+  ode3_flush<C, DROP>(a, lds_raw, G3, G2, GM, GN, G1, slab_row);
 }
 
 
