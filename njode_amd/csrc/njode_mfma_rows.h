@@ -71,11 +71,14 @@ template <class S> struct FwdFrags {
 #pragma unroll
       for (int q = 0; q < S::Q1; ++q) A2[mt][q] = frag[(S::F2 + mt * S::Q1 + q) * 64 + l];
     }
+    // (one output unit: its weight row W3[0][4q + g], the fragment's row 0, see mnet_fwd)
+    const int l3 = S::OUT == 1 ? (lane & 48) : lane;
 #pragma unroll
     for (int mt = 0; mt < S::MTO; ++mt)
 #pragma unroll
-      for (int q = 0; q < S::Q1; ++q) A3[mt][q] = frag[(S::F3 + mt * S::Q1 + q) * 64 + lane];
+      for (int q = 0; q < S::Q1; ++q) A3[mt][q] = frag[(S::F3 + mt * S::Q1 + q) * 64 + l3];
   }
+  NJ_DEV float r3(int q) const { return A3[0][q]; }
   NJ_DEV void begin() const {}
   NJ_DEV float a1(int mt, int q) const { return A1[mt][q]; }
   NJ_DEV float a2(int mt, int q) const { return A2[mt][q]; }
@@ -87,7 +90,14 @@ template <class S> struct LdsFrags {
   lfp base;   // this lane's column of the block's fragment image: base[f * 64]
   lfp cur;
   int de;     // edge rows: their 4x4x1 operands are the edge tile's vectors at lane + de
-  NJ_DEV void init(lfp img, int lane) { base = img + lane; cur = base; de = edge_lane(lane) - lane; }
+  int dr;     // one output unit: its weight row = row 0 of the output fragment, at lane 16 g
+  NJ_DEV void init(lfp img, int lane) {
+    base = img + lane;
+    cur = base;
+    de = edge_lane(lane) - lane;
+    dr = (lane & 48) - lane;
+  }
+  NJ_DEV float r3(int q) const { return cur[(S::F3 + q) * 64 + dr]; }
   // copy all S::NALL fragment vectors of the network from global into LDS (whole block)
   static NJ_DEV void stage(lfp img, const float* frag, int tid, int nthreads) {
     for (int i = tid; i < S::NALL * 64; i += nthreads) img[i] = frag[i];
@@ -217,6 +227,22 @@ template <class S> struct GradTiles {
           }
         }
       }
+    if constexpr (S::OUT == 1) {
+      // (mnet_bwd's one-output form: element q of G3[0] is this lane's chain's part of
+      // dW3[0][4q + g]; the 16 chains of a lane group are summed here, once per block)
+#pragma unroll
+      for (int q = 0; q < S::Q1; ++q) {
+        float v = G3[0][q / 4][q % 4];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const int ui = 4 * q + g;
+        if (c == 0) {
+          if (ui < S::W) W3[ui] = v;
+          else if (ui == S::W) b3[0] = v;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int mt = 0; mt < S::MTO; ++mt)
 #pragma unroll
@@ -259,6 +285,21 @@ NJ_DEV void mnet_fwd(FP& F, const float (&b0)[S::Q0], float (&a1)[S::Q1],
       acc[mt] = mt == S::ET ? mfma1(F.e2(q), a1[q], acc[mt]) : mfma4(F.a2(mt, q), a1[q], acc[mt]);
   if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
   hidden_from_acc_g<S::MT1, S::Q1, S::W, ACT, DROP>(acc, a2, k2, inv_keep, g);
+  if constexpr (S::OUT == 1) {
+    // One output unit (the 1-d models' readout): a 16-row tile per k-step for one row is 13
+    // MFMAs = 416 cycles; on the vector pipe it is 13 FMAs with the weight row W3[0][4q + g] + the
+    // sum over the four lane groups = ~70.  EVERY lane gets the value (register 0; D-layout asks
+    // for it in lane group 0 only, the other groups' units 1 - 3 do not exist and are never read).
+    float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < S::Q1; q += 2) {
+      p0 = fmaf(F.r3(q), a2[q], p0);
+      if (q + 1 < S::Q1) p1 = fmaf(F.r3(q + 1), a2[q + 1], p1);
+    }
+    const float p = p0 + p1;
+    out[0] = f32x4{edge_reduce(p, p), 0.0f, 0.0f, 0.0f};
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < S::MTO; ++mt) out[mt] = z;
 #pragma unroll
@@ -281,18 +322,35 @@ NJ_DEV void mnet_bwd(FP& Bf, GradTiles<S>& G, lfp img_d, lfp img_a,
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc[S::MT1];
   Bf.begin();
-  img_write<S::QO>(img_d, dout, g, c);
-  img_write<S::Q1>(img_a, a2, g, c);
-  wave_lds_sync();
-  dw_accumulate<S::MTO, S::NT1>(img_d, img_a, G.G3, g, c);
+  if constexpr (S::OUT == 1) {
+    // one output unit: dW3[0][4q + g] += dy a2[q] per chain (the chains are summed when the block
+    // flushes, GradTiles::flush) and W3^T dy is a scaling of the weight row -- no images, no MFMAs
+    const float d0 = g == 0 ? dout[0] : 0.0f;
+    const float dyc = edge_reduce(d0, d0);          // the chain's dy in all four lane groups
 #pragma unroll
-  for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
 #pragma unroll
-  for (int q = 0; q < S::QO; ++q)
+    for (int q = 0; q < S::Q1; ++q) {
+      G.G3[0][q / 4][q % 4] = fmaf(dyc, a2[q], G.G3[0][q / 4][q % 4]);
+      if (q < S::QW) {
+        const float w = Bf.r3(q);
+        acc[q / 4][q % 4] = (4 * q + 3 < S::W || 4 * q + g < S::W) ? w * dyc : 0.0f;
+      }
+    }
+  } else {
+    img_write<S::QO>(img_d, dout, g, c);
+    img_write<S::Q1>(img_a, a2, g, c);
+    wave_lds_sync();
+    dw_accumulate<S::MTO, S::NT1>(img_d, img_a, G.G3, g, c);
 #pragma unroll
-    for (int mt = 0; mt < S::MT1; ++mt)
-      acc[mt] = mt == S::ET ? mfma1(Bf.eb3(q), dout[q], acc[mt]) : mfma4(Bf.b3(mt, q), dout[q], acc[mt]);
-  if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
+    for (int mt = 0; mt < S::MT1; ++mt) acc[mt] = z;
+#pragma unroll
+    for (int q = 0; q < S::QO; ++q)
+#pragma unroll
+      for (int mt = 0; mt < S::MT1; ++mt)
+        acc[mt] = mt == S::ET ? mfma1(Bf.eb3(q), dout[q], acc[mt]) : mfma4(Bf.b3(mt, q), dout[q], acc[mt]);
+    if constexpr (S::ER != 0) acc[S::ET] = edge_tile<S::ER>(acc[S::ET], g);
+  }
   float d2[S::QW];
   hidden_delta_g<S::MT1, S::Q1, S::QW, ACT, DROP>(acc, a2, d2, k2, inv_keep, keepf);
   wave_lds_sync();
@@ -436,6 +494,19 @@ NJ_DEV void dec_input(const float* hp, float (&b0)[S::Q0], int g) {
 template <class C, class S>
 NJ_DEV void dec_collect(lfp img, const f32x4 (&out)[S::MTO], const float* hp, float (&y)[C::DO],
                         int g, int c) {
+  if constexpr (C::DO == 1) {   // (one output unit: mnet_fwd leaves it in EVERY lane, no image)
+    float v = out[0][0];
+    if constexpr (C::DEC_CASE == 1) {
+      v += hp[0];
+    } else if constexpr (C::DEC_CASE == 2) {
+      float s = 0.0f;
+#pragma unroll
+      for (int cc = 0; cc < C::H; ++cc) s += hp[cc];
+      v += s * (1.0f / C::H);
+    }
+    y[0] = v;
+    return;
+  }
   float o[S::QO];
 #pragma unroll
   for (int q = 0; q < S::QO; ++q) o[q] = out[q / 4][q % 4];

@@ -7,8 +7,8 @@ run() {
 }
 run A=0
 for b in 1024 2048 2560 3072; do run NJODE_BWD_BLOCKS=$b; done
-for s in 32 96 128; do run NJODE_SPLIT_BWD_BLOCKS=$s; done
-for r in 1.5 1.75 2.0 2.5; do run NJODE_SPLIT_R_BWD=$r; done
+for s in 16 24 48 64 96; do run NJODE_SPLIT_BWD_BLOCKS=$s; done
+for r in 1.75 2.0 2.5 2.75 3.0; do run NJODE_SPLIT_R_BWD=$r; done
 for b in 2048 4096 6144; do run NJODE_FWD_BLOCKS=$b; done
 for s in 64 128 192; do run NJODE_SPLIT_FWD_BLOCKS=$s; done
-for r in 1.75 2.0 2.5 2.75; do run NJODE_SPLIT_R_FWD=$r; done
+for r in 1.5 1.75 2.25 2.5; do run NJODE_SPLIT_R_FWD=$r; done
