@@ -155,9 +155,10 @@ typedef struct NjodeBatch {
 
 /* 1 if the library runs `dims`, else 0.  Two kernel families stand behind the same entry
  * points: shape-specialised kernels for the shapes of the build table (njode_build_info lists
- * them: the demo / PhysioNet / convergence-study shapes with widths < 64, the GRU jump), and
- * the shape-generic matrix-core kernels (njode_gen.h) for everything else without use_rnn:
- * any sizes, widths up to NJODE_GEN_MAX_WIDTH, per-network descriptions (per_net = 1). */
+ * them: the demo / PhysioNet / convergence-study shapes with widths < 64, the demo shape with
+ * the GRU jump), and the shape-generic matrix-core kernels (njode_gen.h) for everything else:
+ * any sizes, widths up to NJODE_GEN_MAX_WIDTH (a GRU cell: 4 x hidden_size), per-network
+ * descriptions (per_net = 1), use_rnn on unmasked models. */
 #define NJODE_GEN_MAX_WIDTH 1024
 int njode_supported(const NjodeDims* dims);
 

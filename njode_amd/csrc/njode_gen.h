@@ -5,7 +5,7 @@
 // a layer wider than 63 units does not fit.  This family takes the shape at RUN TIME:
 // any input / hidden / output size, per network any number of hidden layers (<= GEN_MAXL - 1 = NJODE_MAX_HIDDEN)
 // of any widths with tanh or relu each, the three networks independent of each other, masked or
-// not, every residual case, dropout.  It serves every shape the build table has no
+// not, every residual case, dropout, and (round 4) the GRU jump of use_rnn models (gru_* below).  It serves every shape the build table has no
 // specialisation for (reference grids: widths 80 ... 400, nn_desc = None with hidden_size 50 /
 // 100, the climate shape d = 5: NJODE/parallel_train.py:304-305, 366-371, 433-470, 609, 650,
 // 712).  Masked models, return_path and get_loss = False run the lockstep plan of this file (one
@@ -52,6 +52,7 @@ struct GLayer {
   int QTp, MTT;         // transposed: k-steps over the outputs (padded), tiles over the inputs
   int a_row, d_row;     // record rows: this layer's INPUT vector / the delta of its OUTPUT
   int per, pert;        // output tiles per wave of the launch: forward / transposed product
+  int kind;             // 0: a Linear layer; 1: the GRU cell's two Linear maps as ONE layer (gru_w)
 };
 struct GNet {
   int nl;               // layers = hidden layers + 1
@@ -59,11 +60,54 @@ struct GNet {
   int n_in, n_out;
   GLayer l[GEN_MAXL];
 };
+struct GNet1 {          // a one-layer "network" (same members: net_forward / net_backward take either)
+  int nl, rec_rows, n_in, n_out;
+  GLayer l[1];
+};
+
+// ---- GRU jump (use_rnn; reference models.py:202-217: h[i_obs] = GRUCell(tanh(X_obs), tanh(h[i_obs]))) ----
+// torch.nn.GRUCell:  r = sig(W_ir x + b_ir + W_hr h + b_hr),  z = sig(W_iz x + b_iz + W_hz h + b_hz),
+//                    n = tanh(W_in x + b_in + r (W_hn h + b_hn)),  h' = (1 - z) n + z h.
+// Here the two Linear maps are ONE layer of the family's machinery: input [x (D); h (H); 1], output
+//   rows [0, H): r's pre-activation   [H, 2H): z's   [2H, 3H): W_in x + b_in   [3H, 4H): W_hn h + b_hn
+// -- a block matrix with zeros where the cell has no weight (a jump is rare next to the Euler
+// steps; the zeros cost nothing that matters) -- so fragment tables, records, the transposed
+// product and the weight-gradient GEMM are the ones every other layer uses; only the value of
+// entry (o, i) (gru_w) and where its gradient goes (gru_dw_store) are the cell's own.
+// Parameters at w_off, state_dict order: weight_ih [3H][D], weight_hh [3H][H], bias_ih [3H], bias_hh [3H].
+NJ_DEV float gru_w(const float* __restrict__ P, const GLayer& L, int o, int i) {
+  const int H = L.n_out >> 2, D = L.n_in - H;
+  const float *Wih = P + L.w_off, *Whh = Wih + 3 * H * D, *bih = Whh + 3 * H * H, *bhh = bih + 3 * H;
+  const int gate = o / H, j = o - gate * H;
+  if (gate < 2) return i < D ? Wih[o * D + i] : (i < D + H ? Whh[o * H + (i - D)] : bih[o] + bhh[o]);
+  if (gate == 2) return i < D ? Wih[o * D + i] : (i < D + H ? 0.0f : bih[o]);
+  const int r = 2 * H + j;
+  return i < D ? 0.0f : (i < D + H ? Whh[r * H + (i - D)] : bhh[r]);
+}
+// gradient of entry (o, i) of that layer -> the cell's parameters in a slab row (i == n_in: bias)
+NJ_DEV void gru_dw_store(float* __restrict__ row, int w_off, int n_in, int n_out, int o, int i, float v) {
+  const int H = n_out >> 2, D = n_in - H;
+  float *Wih = row + w_off, *Whh = Wih + 3 * H * D, *bih = Whh + 3 * H * H, *bhh = bih + 3 * H;
+  const int gate = o / H, j = o - gate * H;
+  if (i < D) {
+    if (gate < 3) Wih[o * D + i] = v;
+  } else if (i < D + H) {
+    if (gate < 2) Whh[o * H + (i - D)] = v;
+    else if (gate == 3) Whh[(2 * H + j) * H + (i - D)] = v;
+  } else {
+    if (gate < 2) { bih[o] = v; bhh[o] = v; }
+    else if (gate == 2) bih[o] = v;
+    else bhh[2 * H + j] = v;
+  }
+}
 
 struct GArgs {
   const float* P;
   const float* frag;
   GNet ode, enc, dec;
+  GNet1 gru;             // use_rnn: the GRU cell as one layer (above)
+  int rnn;
+  float* rec_gru;        // [n_times][T] records of the GRU jumps
   int D, H, DO, IN0;
   int masked, curt, enc_case, enc_mult, dec_case, dec_mult, loss_easy;
   int B, T, n_obs, K, n_times;
@@ -311,7 +355,8 @@ NJ_DEV void gstamp(int slot, unsigned long long& t) {
 // rows.  One barrier per layer.  rec != null: the layer inputs are stored to the evaluation
 // record (training calls).  dbase: per-chain dropout hash base of this evaluation (lane's chain
 // = lane & 15)
-NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* rec, bool drop,
+template <class NET>
+NJ_DEV lfp net_forward(const GArgs& a, const NET& N, lfp in, lfp other, float* rec, bool drop,
                        uint32_t dbase) {
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
 #ifdef NJ_GEN_STAMPS
@@ -365,7 +410,8 @@ NJ_DEV lfp net_forward(const GArgs& a, const GNet& N, lfp in, lfp other, float* 
 // returned image (n_in rows), unless !need_input (then the first layer's transposed product is
 // skipped).  The stored activations a layer's epilogue needs (act' and the keep bits) are loaded by
 // the lane that uses them, right behind its tile's fragment loads.  One barrier per layer.
-NJ_DEV lfp net_backward(const GArgs& a, const GNet& N, lfp din, lfp other, float* rec, bool drop,
+template <class NET>
+NJ_DEV lfp net_backward(const GArgs& a, const NET& N, lfp din, lfp other, float* rec, bool drop,
                         bool need_input) {
   const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int l_lo = need_input ? 0 : 1;                    // lowest layer whose transposed product runs
@@ -518,6 +564,55 @@ NJ_DEV void ode_input(const GArgs& a, lfp in, lfp tx, lfp h, lfp tau, float t) {
   }
 }
 
+// ---- GRU jump of the tile ---------------------------------------------------------------------
+NJ_DEV float sigmoid_acc(float x) { return fmaf(0.5f, tanh_acc(0.5f * x), 0.5f); }
+// S.hn <- GRUCell(tanh(S.xr), tanh(S.h)) for every chain (the caller commits the observed ones).
+// rec != null: the layer input [tanh x; tanh h] goes to the record's input rows (net_forward) and
+// the four gate pre-activations to its DELTA rows, where the sweep reads them before it overwrites
+// them with the deltas.
+NJ_DEV void gru_jump_fwd(const GArgs& a, GLds& S, float* rec) {
+  const int tid = threadIdx.x, nth = blockDim.x, D = a.D, H = a.H;
+  for (int e = tid; e < D * 16; e += nth) S.img0[pix(e)] = tanh_acc(S.xr[e]);
+  for (int e = tid; e < H * 16; e += nth) S.img0[pix(D * 16 + e)] = tanh_acc(S.h[e]);
+  if (tid < 16) S.img0[pix((D + H) * 16 + tid)] = 1.0f;                                      // bias unit
+  __syncthreads();
+  lfp out = net_forward(a, a.gru, S.img0, S.img1, rec, false, 0u);
+  if (rec) img_store(rec + (size_t)a.gru.l[0].d_row * 16, out, 4 * H);
+  for (int e = tid; e < H * 16; e += nth) {
+    const float r = sigmoid_acc(out[pix(e)]), z = sigmoid_acc(out[pix(H * 16 + e)]);
+    const float n = tanh_acc(out[pix(2 * H * 16 + e)] + r * out[pix(3 * H * 16 + e)]);
+    const float th = S.img0[pix(D * 16 + e)];
+    S.hn[e] = fmaf(z, th - n, n);                                                             // (1 - z) n + z th
+  }
+  __syncthreads();
+}
+// adjoint of the jump: lam (= S.hn: adjoint of the new state, zero for chains without an observation)
+// -> S.hn = adjoint of the state before the jump through the cell; deltas into the record.
+NJ_DEV void gru_jump_bwd(const GArgs& a, GLds& S, float* rec) {
+  const int tid = threadIdx.x, nth = blockDim.x, D = a.D, H = a.H;
+  const float* pre = rec + (size_t)a.gru.l[0].d_row * 16;       // the forward's gate pre-activations
+  const float* gin = rec + (size_t)a.gru.l[0].a_row * 16;       // [tanh x; tanh h]
+  for (int e = tid; e < H * 16; e += nth) {
+    const float lam = S.hn[e];
+    const float gh = pre[3 * H * 16 + e], th = gin[D * 16 + e];
+    const float r = sigmoid_acc(pre[e]), z = sigmoid_acc(pre[H * 16 + e]);
+    const float n = tanh_acc(pre[2 * H * 16 + e] + r * gh);
+    const float dnp = lam * (1.0f - z) * (1.0f - n * n);        // d / d (pre-activation of n)
+    S.img0[pix(e)] = dnp * gh * r * (1.0f - r);
+    S.img0[pix(H * 16 + e)] = lam * (th - n) * z * (1.0f - z);
+    S.img0[pix(2 * H * 16 + e)] = dnp;
+    S.img0[pix(3 * H * 16 + e)] = dnp * r;
+    S.hn[e] = lam * z * (1.0f - th * th);                       // the direct path h' = ... + z tanh(h)
+  }
+  __syncthreads();
+  lfp din = net_backward(a, a.gru, S.img0, S.img1, rec, false, true);
+  for (int e = tid; e < H * 16; e += nth) {
+    const float th = gin[D * 16 + e];
+    S.hn[e] = fmaf(din[pix(D * 16 + e)], 1.0f - th * th, S.hn[e]);
+  }
+  __syncthreads();
+}
+
 // =============================================================================================
 // forward: one workgroup per tile of 16 paths (models.py:379-518)
 // =============================================================================================
@@ -651,12 +746,16 @@ __global__ void __launch_bounds__(1024) k_gen_fwd(GArgs a) {
           }
         }
         __syncthreads();
-        for (int e = tid; e < a.D * 16; e += nth)
-          S.xin[e] = a.masked ? S.xr[e] * S.mk[e] + (1.0f - S.mk[e]) * S.ybj[e] : S.xr[e];
-        __syncthreads();
-        enc_input(a, S.img0, S.xin, S.mk);
-        __syncthreads();
-        {
+        if (a.rnn) {
+          // h_new = GRUCell(tanh(X_obs), tanh(h))  (models.py:202-217; unmasked models only)
+          float* rec = a.save ? a.rec_gru + jrec * a.gru.rec_rows * 16 : nullptr;
+          gru_jump_fwd(a, S, rec);
+        } else {
+          for (int e = tid; e < a.D * 16; e += nth)
+            S.xin[e] = a.masked ? S.xr[e] * S.mk[e] + (1.0f - S.mk[e]) * S.ybj[e] : S.xr[e];
+          __syncthreads();
+          enc_input(a, S.img0, S.xin, S.mk);
+          __syncthreads();
           float* rec = a.save ? a.rec_enc + jrec * a.enc.rec_rows * 16 : nullptr;
           lfp out = net_forward(a, a.enc, S.img0, S.img1, rec, a.drop != 0,
                                 drop_base(a.dc, gidc, (uint32_t)k, G_NET_ENC));
@@ -841,11 +940,14 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
         }
         __syncthreads();
       }
+      // h_new = GRUCell(tanh x, tanh h_pre): a second path into the state before the jump (left in
+      // lam_hn for the commit below)
+      if (a.rnn) gru_jump_bwd(a, S, a.rec_gru + jrec * a.gru.rec_rows * 16);
       // h_new = encoder(x_in, M)
       float* rec_e = a.rec_enc + jrec * a.enc.rec_rows * 16;
-      img_put(S.img0, lam_hn, a.H);
+      if (!a.rnn) img_put(S.img0, lam_hn, a.H);
       __syncthreads();
-      {
+      if (!a.rnn) {
         lfp din = net_backward(a, a.enc, S.img0, S.img1, rec_e, drop, a.masked != 0);
         if (a.masked) {
           const float* ein = rec_e + (size_t)a.enc.l[0].a_row * 16;
@@ -882,7 +984,7 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
             } else if (a.dec_case == 2) {
               v += dybj[(j % a.DO) * 16 + c] * (1.0f / a.dec_mult);
             }
-            lam_h[e] = v;
+            lam_h[e] = a.rnn ? v + lam_hn[e] : v;
           }
         }
         for (int e = tid; e < a.D * 16; e += nth)
@@ -913,6 +1015,7 @@ struct GDw {
   long long n_flagged;   // records [0, n_flagged) are flagged, the rest always active
   int a_row, d_row, n_in, n_out;
   int w_off, b_off;      // destination offsets in a slab row
+  int kind;              // GLayer.kind (1: the GRU cell's combined layer, gru_dw_store)
   int P;                 // slab row length
   int tiles_m, tiles_n;  // 16-unit tiles over outputs / inputs (+ bias column)
   float* slab;           // [gridDim.y][P]
@@ -1021,7 +1124,8 @@ __global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
       for (int rr = 0; rr < 4; ++rr) {
         const int uo = 16 * (tm0 + i) + 4 * g + rr;
         if (uo < d.n_out) {
-          if (ui < d.n_in) row[d.w_off + (size_t)uo * d.n_in + ui] = t[rr];
+          if (d.kind == 1) { if (ui <= d.n_in) gru_dw_store(row, d.w_off, d.n_in, d.n_out, uo, ui, t[rr]); }
+          else if (ui < d.n_in) row[d.w_off + (size_t)uo * d.n_in + ui] = t[rr];
           else if (ui == d.n_in) row[d.b_off + uo] = t[rr];
         }
       }
@@ -1029,7 +1133,7 @@ __global__ void __launch_bounds__(256) k_gen_dw(GDw d) {
 }
 
 // ---- fragment tables ------------------------------------------------------------------------
-struct GPack { int n_layers; GLayer l[3 * GEN_MAXL]; int total; };
+struct GPack { int n_layers; GLayer l[3 * GEN_MAXL + 1]; int total; };
 __global__ void k_gen_pack(const float* __restrict__ P, float* __restrict__ frag, GPack p) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= p.total) return;
@@ -1042,7 +1146,9 @@ __global__ void k_gen_pack(const float* __restrict__ P, float* __restrict__ frag
       const int mt = f / Qq, k = 4 * (f % Qq) + qq;
       const int o = 16 * mt + (lane & 15), i = 4 * k + (lane >> 4);
       float v = 0.0f;
-      if (o < L.n_out) v = i < L.n_in ? P[L.w_off + (size_t)o * L.n_in + i] : (i == L.n_in ? P[L.b_off + o] : 0.0f);
+      if (o < L.n_out && i <= L.n_in)
+        v = L.kind == 1 ? gru_w(P, L, o, i)
+                        : (i < L.n_in ? P[L.w_off + (size_t)o * L.n_in + i] : P[L.b_off + o]);
       frag[idx] = v;
       return;
     }
@@ -1050,7 +1156,8 @@ __global__ void k_gen_pack(const float* __restrict__ P, float* __restrict__ frag
       const int e = idx - L.ft_off, qq = e & 3, lane = (e >> 2) & 63, f = e >> 8, Qq = L.QTp >> 2;
       const int mt = f / Qq, k = 4 * (f % Qq) + qq;
       const int i = 16 * mt + (lane & 15), o = 4 * k + (lane >> 4);
-      frag[idx] = (i < L.n_in && o < L.n_out) ? P[L.w_off + (size_t)o * L.n_in + i] : 0.0f;
+      frag[idx] = (i < L.n_in && o < L.n_out)
+                      ? (L.kind == 1 ? gru_w(P, L, o, i) : P[L.w_off + (size_t)o * L.n_in + i]) : 0.0f;
       return;
     }
   }

@@ -117,7 +117,6 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
   *why = none;
   memset(&m, 0, sizeof(m));
   if (!d) { *why = "null dims"; return false; }
-  if (d->flags & NJODE_F_USE_RNN) { *why = "use_rnn runs on the specialised kernels only"; return false; }
   const int D = d->input_size, H = d->hidden_size, DO = d->output_size;
   if (D <= 0 || H <= 0 || DO <= 0 || D > 512 || H > 1024 || DO > 512) { *why = "sizes out of range"; return false; }
   if (D != DO) { *why = "the loss compares X with the readout: input_size must equal output_size"; return false; }
@@ -154,6 +153,44 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
     *why = "network description out of range (<= 4 hidden layers, widths <= 1024, tanh / relu)";
     return false;
   }
+  a.rnn = (d->flags & NJODE_F_USE_RNN) ? 1 : 0;
+  if (a.rnn) {
+    // the GRU cell as ONE layer [x; h; 1] -> [r, z, W_in x + b_in, W_hn h + b_hn]  (njode_gen.h, gru_w)
+    if (masked) { *why = "use_rnn with masked data is not defined by the reference (models.py:353)"; return false; }
+    if (4 * H > NJODE_GEN_MAX_WIDTH) { *why = "use_rnn: 4 x hidden_size exceeds the widest layer the kernels take"; return false; }
+    GNet1& N = a.gru;
+    N.nl = 1;
+    N.n_in = D + H;
+    N.n_out = 4 * H;
+    GLayer& L = N.l[0];
+    memset(&L, 0, sizeof(L));
+    L.kind = 1;
+    L.n_in = D + H;
+    L.n_out = 4 * H;
+    L.act = -1;
+    L.w_off = p_off;                              // weight_ih, weight_hh, bias_ih, bias_hh
+    L.b_off = p_off + 3 * H * D + 3 * H * H;
+    p_off += 3 * H * D + 3 * H * H + 6 * H;
+    L.Qp = pad_to(cdiv(L.n_in + 1, 4), QU);
+    L.MT = cdiv(L.n_out, 16);
+    L.QTp = pad_to(cdiv(L.n_out, 4), QU);
+    L.MTT = cdiv(L.n_in, 16);
+    L.f_off = f_off;
+    f_off += L.MT * L.Qp * 64;
+    L.ft_off = f_off;
+    f_off += L.MTT * L.QTp * 64;
+    L.a_row = 0;
+    L.d_row = L.n_in;
+    N.rec_rows = L.n_in + L.n_out;
+    int need = 4 * L.Qp;
+    if (4 * L.QTp > need) need = 4 * L.QTp;
+    if (L.n_out + 1 > need) need = L.n_out + 1;
+    if (need > img_rows) img_rows = need;
+    if (L.MT > max_mt) max_mt = L.MT;
+    const int tb = cdiv(L.MT, DW_TM) * cdiv(cdiv(L.n_in + 1, 16), DW_TN);
+    if (tb > max_tb) max_tb = tb;
+    m.pack.l[m.pack.n_layers++] = L;
+  }
   m.P = p_off;
   m.frag_floats = f_off + RING * 256;   // (+ one chunk: the product loop reads whole chunks)
   m.pack.total = f_off;
@@ -178,7 +215,7 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
 struct Layout {
   size_t total = 0;
   size_t sched, jlo, dense, bad, plan_end;
-  size_t frag, loss_terms, slab, rec_ode, rec_enc, rec_dec, ybuf, flags;
+  size_t frag, loss_terms, slab, rec_ode, rec_enc, rec_dec, rec_gru = 0, ybuf, flags;
   // segment plan (unmasked loss calls): plan prefix ...
   size_t t_of_row, item_prev, item_next, item_kbeg, item_len, key, key_sorted, iota, order,
       first_row, last_row, tail_key, tail_key_sorted, iota_b, tail_order, tile_base, sort_tmp;
@@ -214,7 +251,8 @@ bool use_seg(const Model& m, int n_obs, int call_flags) {
   // step lay their buffers out by it and must agree -- the Python class reads NJODE_GEN_PLAN once
   // per step and sets the flag)
   const bool lock_only = (call_flags & NJODE_C_GEN_LOCKSTEP) != 0;
-  return !lock_only && !m.a.masked && n_obs > 0 && (call_flags & NJODE_C_GET_LOSS) &&
+  // (use_rnn: the state after a jump depends on the state before it -- no independent items)
+  return !lock_only && !m.a.masked && !m.a.rnn && n_obs > 0 && (call_flags & NJODE_C_GET_LOSS) &&
          !(call_flags & NJODE_C_RETURN_PATH);
 }
 
@@ -233,7 +271,8 @@ static int gen_paths_per_tile(const Model& m, int B, int nt, int K, int call_fla
     auto bytes = [&](int p) {
       const double T = (double)((B + p - 1) / p);
       return T * ((double)(K > 0 ? K : 1) * m.a.ode.rec_rows +
-                  (double)(nt > 0 ? nt : 1) * (m.a.enc.rec_rows + 2.0 * m.a.dec.rec_rows)) * 64.0;
+                  (double)(nt > 0 ? nt : 1) * (m.a.enc.rec_rows + 2.0 * m.a.dec.rec_rows +
+                                               (m.a.rnn ? m.a.gru.rec_rows : 0))) * 64.0;
     };
     while (pt < 16 && bytes(pt) > 40.0e9) pt *= 2;
   }
@@ -304,6 +343,7 @@ Layout make_layout(const Model& m, int B, int n_obs, int nt, int K, int call_fla
       L.rec_dec = L.take(ntl * T * 2 * m.a.dec.rec_rows * 64);
       L.ybuf = L.take(ntl * T * 2 * m.a.DO * 64);
       L.flags = L.take(ntl * T * 4);
+      if (m.a.rnn) L.rec_gru = L.take(ntl * T * m.a.gru.rec_rows * 64);
     }
   } else {
     L.slab = L.rec_ode = L.rec_enc = L.rec_dec = L.ybuf = L.flags = 0;
@@ -444,6 +484,7 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
     a.rec_dec = (float*)(w + c.L.rec_dec);
     a.ybuf = (float*)(w + c.L.ybuf);
     a.flags = (int*)(w + c.L.flags);
+    a.rec_gru = a.rnn ? (float*)(w + c.L.rec_gru) : nullptr;
   }
   a.want_loss = (call_flags & NJODE_C_GET_LOSS) ? 1 : 0;
   a.want_path = (call_flags & NJODE_C_RETURN_PATH) ? 1 : 0;
@@ -494,6 +535,8 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
         N->l[l].per = cdiv(N->l[l].MT, c.m.nw);
         N->l[l].pert = cdiv(N->l[l].MTT, c.m.nw);
       }
+    a.gru.l[0].per = cdiv(a.gru.l[0].MT, c.m.nw);
+    a.gru.l[0].pert = cdiv(a.gru.l[0].MTT, c.m.nw);
   }
   if (c.L.seg) {
     GSeg& g = c.g;
@@ -656,7 +699,7 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
   const GArgs& a = c.a;
   const long long T = c.L.T, nt = a.n_times;
   const int* n_rec_dev = nullptr;
-  auto dw = [&](const GNet& N, const float* rec, long long n_rec, const int* flags, int flag_div,
+  auto dw = [&](const auto& N, const float* rec, long long n_rec, const int* flags, int flag_div,
                 long long n_flagged) {
     for (int l = 0; l < N.nl; ++l) {
       const GLayer& Ly = N.l[l];
@@ -674,6 +717,7 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
       d.n_out = Ly.n_out;
       d.w_off = Ly.w_off;
       d.b_off = Ly.b_off;
+      d.kind = Ly.kind;
       d.P = c.m.P;
       d.tiles_m = Ly.MT;
       d.tiles_n = cdiv(Ly.n_in + 1, 16);
@@ -692,7 +736,13 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
   } else {
     Prof ps("k_gen_dw", st);
     dw(a.ode, a.rec_ode, (long long)a.K * T, nullptr, 1, 0);
-    dw(a.enc, a.rec_enc, nt * T + T, a.flags, 1, nt * T);
+    if (a.rnn) {
+      // (the encoder only produced the start states; the jumps went through the GRU cell)
+      dw(a.enc, a.rec_enc + (size_t)nt * T * a.enc.rec_rows * 16, T, nullptr, 1, 0);
+      dw(a.gru, a.rec_gru, nt * T, a.flags, 1, nt * T);
+    } else {
+      dw(a.enc, a.rec_enc, nt * T + T, a.flags, 1, nt * T);
+    }
     dw(a.dec, a.rec_dec, nt * T * 2, a.flags, 2, nt * T * 2);
   }
   k_gen_reduce<<<cdiv(c.m.P, 256), 256, 0, st>>>(slab, c.m.S, c.m.P, grad_loss, grad_params);

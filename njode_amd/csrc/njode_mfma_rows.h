@@ -162,9 +162,11 @@ template <class S> struct GradTiles {
   // stores ONE slab row.  Returns true for the wave that holds the sum.
   NJ_DEV bool reduce_block(lfp lds, int wv, int lane) {
     f32x4 __attribute__((address_space(3)))* red = (f32x4 __attribute__((address_space(3)))*)lds;
-    if constexpr (S::ER != 0) {   // (two accumulators each: independent 4x4x1 chains)
+    if constexpr (S::ER != 0) {   // (two accumulators each, independent 4x4x1 chains: flush adds them)
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       GM[0] += GM[1];
       GN[0] += GN[1];
+      GM[1] = GN[1] = z;
     }
     __syncthreads();
     if (wv > 0) for_tiles([&](f32x4& t, int i) { red[((wv - 1) * NG + i) * 64 + lane] = t; });
@@ -198,18 +200,19 @@ template <class S> struct GradTiles {
     if constexpr (S::ER != 0) {
       // GM: register i of lane l = dW2[16 ET + i][l]; GN: = dW2[l][16 ET + i] for l < 16 ET
       const int lane = 16 * g + c;
+      const f32x4 gm = GM[0] + GM[1], gn = GN[0] + GN[1];
 #pragma unroll
       for (int i = 0; i < S::ER; ++i) {
         const int uo = 16 * S::ET + i;
-        if (lane < S::W) W2[uo * S::W + lane] = GM[0][i];
-        else if (lane == S::W) b2[uo] = GM[0][i];
+        if (lane < S::W) W2[uo * S::W + lane] = gm[i];
+        else if (lane == S::W) b2[uo] = gm[i];
       }
       if (lane < 16 * S::ET) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int ui = 16 * S::ET + i;
-          if (ui < S::W) W2[lane * S::W + ui] = GN[0][i];
-          else if (ui == S::W) b2[lane] = GN[0][i];
+          if (ui < S::W) W2[lane * S::W + ui] = gn[i];
+          else if (ui == S::W) b2[lane] = gn[i];
         }
       }
     }

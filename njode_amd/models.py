@@ -470,8 +470,7 @@ class NJODE(torch.nn.Module):
                 'libnjode_hip.so has no gfx950 kernels for input_size={}, hidden_size={}, '
                 'output_size={}, ode/enc/readout nets (n_hidden, widths, acts)={}, masked={}, '
                 'input_current_t={}, residual={}, use_rnn={} (the shape-generic kernels run '
-                'every model without use_rnn whose widths are <= {}; use_rnn needs an entry of '
-                'CONFIGS in njode_amd/build.py).  {}'
+                'every model whose widths are <= {}; with use_rnn 4 x hidden_size too).  {}'
                 .format(self.input_size, self.hidden_size, self.output_size, self._descs,
                         self.masked, self.input_current_t, self.residual_enc_dec,
                         self.use_rnn, 1024, _lib.build_info()))

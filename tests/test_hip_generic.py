@@ -35,9 +35,9 @@ def test_parity_suite_on_the_generic_kernels():
     assert p.returncode == 0, p.stdout[-6000:]
 
 
-def _cfg(d, H, ode, enc, dec, dropout=0.0, **options):
+def _cfg(d, H, ode, enc, dec, dropout=0.0, use_rnn=False, **options):
     return dict(input_size=d, hidden_size=H, output_size=d, ode_nn=ode, readout_nn=dec, enc_nn=enc,
-                use_rnn=False, bias=True, dropout_rate=dropout, options=options)
+                use_rnn=use_rnn, bias=True, dropout_rate=dropout, options=options)
 
 
 def _w(n, act='tanh', layers=2):
@@ -59,6 +59,10 @@ UNMASKED = {
                          _w(33, 'tanh', 5), _w(20, 'relu', 8)), 19),
     'one_layer_easy': (_cfg(2, 6, _w(70, 'tanh', 1), _w(18, 'relu', 1), _w(65, 'tanh', 1),
                             which_loss='easy'), 23),
+    # round 4: the GRU jump (models.py:202-217, 353-356, 460-461) on shapes outside the build table
+    'gru_w80': (_cfg(1, 10, _w(80), _w(80), _w(80), use_rnn=True), 37),
+    'gru_d2_h24': (_cfg(2, 24, _w(33), _w(20, 'relu', 1), _w(72, 'tanh', 3), use_rnn=True,
+                        residual_enc_dec=False), 21),
 }
 
 

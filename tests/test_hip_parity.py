@@ -282,10 +282,11 @@ def test_lockstep_backward_matches_reference_on_unmasked_models(name):
 
 
 def test_unsupported_shape_fails_loudly():
-    """The GRU jump exists for the shapes of the build table only (the shape-generic kernels run
-    everything else without use_rnn): any other GRU shape raises instead of computing something."""
+    """What the library does not run raises instead of computing something: a GRU cell wider than
+    the widest layer of the shape-generic kernels (4 x hidden_size > 1024), more hidden layers than
+    NJODE_MAX_HIDDEN."""
     nn = ((33, 'tanh'), (33, 'tanh'))
-    m = models.NJODE(1, 10, 1, nn, nn, nn, use_rnn=True, options={}).cuda()
+    m = models.NJODE(1, 300, 1, nn, nn, nn, use_rnn=True, options={}).cuda()
     b, meta = bs_batch(8)
     with pytest.raises(NotImplementedError, match='no gfx950 kernels'):
         hip_forward(m, b, meta['dt'], meta['maturity'])

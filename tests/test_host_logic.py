@@ -247,7 +247,14 @@ def test_library_loads_and_exports_declared_symbols():
         (10 * 64 + 64) + (64 * 32 + 32) + (32 * 48 + 48) + (48 * 6 + 6) + (2 * 30 + 30) + (30 * 6 + 6) + (6 * 2 + 2)
     # ... except what no kernel family covers: a GRU jump outside the table, residual sizes
     # that do not divide (the reference raises ValueError for those, models.py:243-249)
-    d2 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_USE_RNN)
+    # (round 4: the shape-generic kernels run the GRU jump for any shape ...)
+    d5 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_USE_RNN)
+    assert L.njode_supported(ctypes.byref(d5)) == 1
+    assert L.njode_param_count(ctypes.byref(d5)) == \
+        (12 * 50 + 50) + (50 * 50 + 50) + (50 * 7 + 7) + (3 * 50 + 50) + (50 * 50 + 50) + (50 * 7 + 7) + \
+        (7 * 50 + 50) + (50 * 50 + 50) + (50 * 3 + 3) + (21 * 3 + 21 * 7 + 21 + 21)
+    # ... but not with masked data, which the reference leaves undefined (models.py:353)
+    d2 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_USE_RNN | _lib.F_MASKED)
     assert L.njode_supported(ctypes.byref(d2)) == 0
     assert L.njode_supported(ctypes.byref(_lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_RESIDUAL))) == 0
     need = ctypes.c_size_t(0)
