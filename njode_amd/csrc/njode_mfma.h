@@ -399,10 +399,15 @@ NJ_DEV void hidden_delta_g(const f32x4 (&acc)[MT1], const float (&av)[Q1], float
 #pragma unroll
   for (int q = 0; q < QW; ++q) {
     const float gsum = acc[q / 4][q % 4];
-    if constexpr (DROP)
-      dv[q] = ((keep >> q) & 1) ? gsum * inv_keep * dact_f<ACT>(av[q] * keepf) : 0.0f;
-    else
+    if constexpr (DROP) {
+      // av = act / keep:  (1 / keep) (1 - (av keep)^2) = 1 / keep - keep av^2   (one fma)
+      float f;
+      if constexpr (ACT == ACT_TANH) f = fmaf(av[q] * av[q], -keepf, inv_keep);
+      else f = inv_keep * dact_f<ACT>(av[q] * keepf);
+      dv[q] = ((keep >> q) & 1) ? gsum * f : 0.0f;
+    } else {
       dv[q] = gsum * dact_f<ACT>(av[q]);
+    }
   }
 }
 template <class C, bool DROP>

@@ -139,8 +139,10 @@ def _args(b, dt, T):
     return (d['times'], d['time_ptr'], d['X'], d['obs_idx'], dt, T, d['start_X'], d['n_obs_ot'])
 
 
-def test_generic_dropout_gradient_matches_finite_differences():
-    cfg = _cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1)
+@pytest.mark.parametrize('use_rnn', [False, True])
+def test_generic_dropout_gradient_matches_finite_differences(use_rnn):
+    """(use_rnn: the GRU jump on the lockstep plan, dropout in the three networks around it)"""
+    cfg = _cfg(1, 10, _w(100), _w(100), _w(100), dropout=0.1, use_rnn=use_rnn)
     b, meta = bs_batch(200, seed=6)
     torch.manual_seed(0)
     m = hip_model(cfg).train()
