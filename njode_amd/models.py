@@ -248,6 +248,14 @@ def _desc_of(nn_desc):
     return (len(nn_desc), widths, acts)
 
 
+def _raw_current_stream(dev):
+    """hipStream_t of torch's current stream on ``dev`` as an int, without building a Stream object."""
+    get = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if get is not None and dev.index is not None:
+        return get(dev.index)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
 class NJODE(torch.nn.Module):
     """NJ-ODE model (reference ``models.py:280-584``), HIP-backed."""
 
@@ -494,9 +502,11 @@ class NJODE(torch.nn.Module):
 
     def _make_call(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
                    return_path, get_loss, until_T, M, save_bwd, plan_key=None, plan_only=False,
-                   want_hT=True, plan=None, rows_in_fwd=False):
+                   want_hT=True, plan=None, rows_in_fwd=False, stream=None):
         """``plan_key`` = the caller's original ``(obs_idx, time_ptr)`` objects (looked up among
-        the prefetched plans by identity); ``plan`` = a handle returned by ``prefetch_plan``."""
+        the prefetched plans by identity); ``plan`` = a handle returned by ``prefetch_plan``;
+        ``stream`` = the caller's current stream if it already looked it up (a lookup costs
+        several microseconds of a step that, at the reference's batch sizes, the host bounds)."""
         L = _lib.lib()
         dev = start_X.device
         if dev.type != 'cuda':
@@ -564,7 +574,7 @@ class NJODE(torch.nn.Module):
         if plan is not None:
             cb.plan = plan.buf.data_ptr()
             flags |= _lib.C_PLAN_READY | (plan.flags & _lib.C_NEED_HT)
-            torch.cuda.current_stream().wait_event(plan.done)
+            (stream if stream is not None else torch.cuda.current_stream(dev)).wait_event(plan.done)
             keep.append(plan)
         need = ctypes.c_size_t(0)
         _lib.check(L.njode_workspace_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
@@ -654,14 +664,15 @@ class NJODE(torch.nn.Module):
         if self._plan_stream is None:
             self._plan_stream = torch.cuda.Stream(device=dev)
         side = self._plan_stream
-        side.wait_stream(torch.cuda.current_stream())   # the batch's arrays are ready by now
-        with torch.cuda.stream(side):
-            rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs), flags,
-                                  buf.data_ptr(), buf.numel(), side.cuda_stream)
-            self._ring.release_after(slot_i, side)
-            _lib.check(rc)
-            done = torch.cuda.Event()
-            done.record(side)
+        side.wait_stream(torch.cuda.current_stream(dev))   # the batch's arrays are ready by now
+        # (the library call, the ring and the event all take the stream explicitly: no
+        # `with torch.cuda.stream(side)` -- entering and leaving it costs ~15 us of host time)
+        rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs), flags,
+                              buf.data_ptr(), buf.numel(), side.cuda_stream)
+        self._ring.release_after(slot_i, side)
+        _lib.check(rc)
+        done = torch.cuda.Event()
+        done.record(side)
         plan = _Plan()
         plan.buf, plan.done, plan.flags, plan.sizes, plan.keep = buf, done, flags, (B, n_obs, nt, K), keep
         plan.pool = self._plan_pool
@@ -770,10 +781,12 @@ class NJODE(torch.nn.Module):
         rows and the backward, which evaluates the same readouts anyway, writes the loss.
         Used by the build's harness and bench."""
         grad = self.flat_grad()
+        dev = start_X.device
+        stream = torch.cuda.current_stream(dev)      # (one lookup per step: ~7 us each)
         call, sched, slot_i, B = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False,
-            M, save_bwd=True, plan_key=(obs_idx, time_ptr), want_hT=self.masked, plan=plan)
-        dev = start_X.device
+            M, save_bwd=True, plan_key=(obs_idx, time_ptr), want_hT=self.masked, plan=plan,
+            stream=stream)
         # (always written: sum of the terms; data parallel: written INTO the gradient bucket, see
         # loss_slot())
         loss = (self.loss_slot() if self.dp_loss_in_bucket
@@ -783,7 +796,6 @@ class NJODE(torch.nn.Module):
         hT = (torch.empty(B, self.hidden_size, dtype=torch.float32, device=dev)
               if self.masked else None)
         call.flags |= _lib.C_LOSS_IN_BWD
-        stream = torch.cuda.current_stream(dev)      # (one lookup per step: ~7 us each)
         self._last_stream = stream
         try:
             self._run_forward(call, hT, loss, None, None, slot_i, stream)
@@ -872,7 +884,7 @@ class FusedAdam:
             flat.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
             self.exp_avg_sq.data_ptr(), flat.numel(), self.lr, self.betas[0], self.betas[1],
             self.eps, self.weight_decay, self.step_count, 1.0,
-            torch.cuda.current_stream().cuda_stream))
+            _raw_current_stream(flat.device)))
 
     def allreduce_ms(self):
         """Mean device time of the gradient all-reduce since the last call (``time_allreduce``
