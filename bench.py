@@ -356,8 +356,11 @@ def spawn_ranks(n, argv, rank_timeout=900.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults: 20 untimed + 100 timed steps (~0.1 s).  The clocks of an idle MI355X take tens of
+    # steps of this size to settle: from a cold start a 3 + 20 window reads ~4 % slow
+    # (0.921 - 0.933 ms against 0.889 ms per step on one box, profiles/r04_bench_window.txt)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--paths-per-gpu', type=int, default=20000,
                     help='weak scaling: every rank holds this many paths (default)')
     ap.add_argument('--global-paths', type=int, default=0,
