@@ -322,24 +322,41 @@ def spawn_ranks(n, argv, rank_timeout=900.0):
            os.path.abspath(__file__)] + list(argv)
     import signal
     import tempfile
+
+    def kill_group(child):
+        """SIGTERM, then SIGKILL, to the launcher AND its ranks (they are a session of their own)."""
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                return
+            try:
+                child.wait(timeout=10)
+                return
+            except subprocess.TimeoutExpired:
+                continue
+
     with tempfile.TemporaryFile(mode='w+') as err:
         child = subprocess.Popen(cmd, env=env, stderr=err, start_new_session=True)
+        # The ranks do not share this process's group (start_new_session), so a terminal Ctrl-C or
+        # a SIGTERM to bench.py does not reach them by itself: whatever ends the wait below --
+        # the timeout, KeyboardInterrupt, a SIGTERM (turned into SystemExit here), any other
+        # exception -- takes the whole group down before it propagates.  Nothing is re-executed.
+        def on_term(signum, frame):
+            raise SystemExit(128 + signum)
+        old_term = signal.signal(signal.SIGTERM, on_term)
         try:
             rc = child.wait(timeout=rank_timeout if rank_timeout and rank_timeout > 0 else None)
         except subprocess.TimeoutExpired:
             rc = 124
-            for sig in (signal.SIGTERM, signal.SIGKILL):
-                try:
-                    os.killpg(child.pid, sig)      # the launcher AND its ranks (own session)
-                except ProcessLookupError:
-                    break
-                try:
-                    child.wait(timeout=10)
-                    break
-                except subprocess.TimeoutExpired:
-                    continue
+            kill_group(child)
             print('bench.py: the {} ranks did not finish within {:.0f} s (--rank-timeout): process '
                   'group killed'.format(n, rank_timeout), file=sys.stderr)
+        except BaseException:
+            kill_group(child)
+            raise
+        finally:
+            signal.signal(signal.SIGTERM, old_term)
         err.seek(0)
         text = err.read()
     if rc != 0:

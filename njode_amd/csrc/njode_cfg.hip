@@ -469,3 +469,12 @@ hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, int od
 #endif
 
 }  // namespace njode
+
+#if defined(NJ_BWD_STAMPS) && NJ_PART == 1
+// diagnostic build only (tools/ubench/bwd_stamps.sh): the per-wave stamps of k_ode_bwd_mixed
+extern "C" int njode_debug_bwd_stamps(unsigned long long* dst, unsigned long long n_words) {
+  const size_t cap = sizeof(njode::g_bwd_stamps) / 8;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(njode::g_bwd_stamps),
+                                  (n_words < cap ? n_words : cap) * 8);
+}
+#endif

@@ -150,7 +150,7 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
   if (!build_net(a.ode, a.IN0, H, nets[0], p_off, f_off, m.pack, img_rows, max_mt, max_tb) ||
       !build_net(a.enc, masked ? 2 * D : D, H, nets[1], p_off, f_off, m.pack, img_rows, max_mt, max_tb) ||
       !build_net(a.dec, H, DO, nets[2], p_off, f_off, m.pack, img_rows, max_mt, max_tb)) {
-    *why = "network description out of range (<= 4 hidden layers, widths <= 1024, tanh / relu)";
+    *why = "network description out of range (<= 8 hidden layers, widths <= 1024, tanh / relu)";
     return false;
   }
   a.rnn = (d->flags & NJODE_F_USE_RNN) ? 1 : 0;
@@ -261,7 +261,8 @@ bool use_seg(const Model& m, int n_obs, int call_flags) {
 // of 50 paths is 4 tiles on a 256-CU chip: fewer paths per tile (the other chains idle) shorten
 // the serial chain of every tile -- same reasoning as q4_paths_per_tile of the specialised masked
 // kernels (njode_api.hip).  The smallest power of two that keeps the tile count within the CUs
-// and the training records (one per Euler step / jump and TILE) within 40 GB (of the 288).  NJODE_GEN_PT: A/B.
+// and the training records (one per Euler step / jump and TILE) within record_budget_bytes()
+// (njode_gen_host.h: 16 GB or 1/8 of the device's memory; round 4 allowed 40 GB).  NJODE_GEN_PT: A/B.
 static int gen_paths_per_tile(const Model& m, int B, int nt, int K, int call_flags) {
   static const int env = getenv("NJODE_GEN_PT") ? atoi(getenv("NJODE_GEN_PT")) : 0;
   if (env == 1 || env == 2 || env == 4 || env == 8 || env == 16) return env;
@@ -274,7 +275,8 @@ static int gen_paths_per_tile(const Model& m, int B, int nt, int K, int call_fla
                   (double)(nt > 0 ? nt : 1) * (m.a.enc.rec_rows + 2.0 * m.a.dec.rec_rows +
                                                (m.a.rnn ? m.a.gru.rec_rows : 0))) * 64.0;
     };
-    while (pt < 16 && bytes(pt) > 40.0e9) pt *= 2;
+    const double budget = record_budget_bytes();
+    while (pt < 16 && bytes(pt) > budget) pt *= 2;
   }
   return pt;
 }

@@ -8,6 +8,15 @@
 #include "../../include/njode_hip.h"
 
 namespace njode {
+
+// Budget of the per-(tile, Euler step) TRAINING RECORDS of the masked lockstep kernels, which grow
+// up to 16x when a tile holds fewer than 16 paths (q4_paths_per_tile, gen_paths_per_tile): the
+// smaller of NJODE_REC_BUDGET_GB (default 16) and 1/8 of the device's TOTAL memory.  Total, not
+// free: the layout is computed twice per call (njode_workspace_bytes, then the call itself, after
+// the caller has allocated the workspace) and must come out the same both times.  Defined in
+// njode_api.hip.
+double record_budget_bytes();
+
 namespace gen {
 
 bool gen_supported(const NjodeDims* dims);

@@ -121,6 +121,10 @@ struct KArgs {
   float* loss_terms;
   float* slab;
   float* trash;  // [64 * max(H, D)] scratch target for the stores of inactive lanes
+  // tile queue of the mixed ODE backward (njode_ode2.h): [0] four-wave tiles, [1] bulk tiles,
+  // [2] finished blocks; tile_q_on: this launch pops its tiles (else static snake rounds)
+  int* tile_q;
+  int tile_q_on;
   int n_waves;      // persistent gradient kernels (VALU): waves == slab rows
   int n_waves_ode;  // same for the ODE backward kernel
   int n_waves_rows; // same for the row backward kernels on the matrix cores

@@ -391,7 +391,7 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
 // shared: X1 (a1 / its image), X2 (d2 / its image), reduce buffer; per wave: images of d3,
 // own a2 tile, own d1 tile, b0
 template <class C> struct OdeBwdSplitLds {
-  static constexpr int FLOATS = 2 * XFLOATS + 4 * MF<C>::QH * 64 + 4 * 4 * TFLOATS;
+  static constexpr int FLOATS = 2 * XFLOATS + 4 * MF<C>::QH * 64 + 4 * 4 * TFLOATS + 64;   // (+ the tile queue's hand-over word)
 };
 // C (split): reverse Euler sweep, d loss / d ODE params.  Block `worker` of `n_workers` walks
 // the tiles [tile0, tile1); one slab row per block, wave w flushes the tiles it owns.
@@ -579,9 +579,11 @@ template <class C> struct SplitFragsT {
 };
 
 // C (split, stored activations): as ode_bwd_split, the hidden activations loaded
-template <class C, bool DROP>
+// QUEUE (njode_ode2.h, tile queue): the block pops tiles [tile0, tile1) from tile_q[0], then -- a
+// four-wave block runs any tile -- helps with the bulk's [tile1, n_all) from tile_q[1]
+template <class C, bool DROP, bool QUEUE = false>
 NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers, int tile0, int tile1,
-                          int slab_row) {
+                          int slab_row, int n_all = 0) {
   using M = MF<C>;
   using NL = typename C::Ode;
   constexpr int NT1 = 4;
@@ -603,10 +605,36 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
   f32x4 G3[1][1] = {{z}}, G2[1][NT1] = {{z, z, z, z}}, G1[1][1] = {{z}};
   float* const trash = a.trash + lane * C::H;
   const int n_tiles = tile1 - tile0;
-  for (int round = 0; round * n_workers < n_tiles; ++round) {
-    const int rel = snake_tile(round, worker, n_workers);
-    if (rel >= n_tiles) continue;
-    const int tile = tile0 + rel;
+  BWD_STAMP(1, wall_clock64());
+  // (QUEUE: wave 0 pops -- one tile ahead, so the atomic's round trip hides behind the sweep -- and
+  // hands the tile to the block through one LDS word)
+  int __attribute__((address_space(3)))* qword = (int __attribute__((address_space(3)))*)(lds_raw + OdeBwdSplitLds<C>::FLOATS - 64);
+  int q_phase = 0;
+  auto pop = [&]() -> int {
+    if (q_phase == 0) {
+      const int t = queue_pop(a.tile_q);
+      if (t < n_tiles) return tile0 + t;
+      q_phase = 1;
+    }
+    return tile1 + queue_pop(a.tile_q + 1);
+  };
+  int q_next = 0;
+  if constexpr (QUEUE) { if (w == 0) q_next = pop(); }
+  int n_done = 0, n_steps_done = 0;
+  for (int round = 0; QUEUE || round * n_workers < n_tiles; ++round) {
+    int tile;
+    if constexpr (QUEUE) {
+      if (w == 0 && lane == 0) *qword = q_next;
+      block_lds_barrier();
+      tile = uniform(*qword);
+      block_lds_barrier();
+      if (tile >= n_all) break;
+      if (w == 0) q_next = pop();
+    } else {
+      const int rel = snake_tile(round, worker, n_workers);
+      if (rel >= n_tiles) continue;
+      tile = tile0 + rel;
+    }
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
     Item<C> it;
@@ -619,6 +647,8 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
       lam[q] = (valid && u < C::H) ? v : 0.0f;
     }
     const int nmax = uniform(wave_max(it.n));   // (scalar step loop, scalar record address)
+    ++n_done;
+    n_steps_done += nmax;
     // the record and the schedule values of step s - 1 are loaded while step s runs, RAW
     SplitRecRaw<C> nx;
     nx.zero();
@@ -716,6 +746,10 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
     }
   }
 
+  BWD_STAMP(2, wall_clock64());
+  BWD_STAMP(4, (unsigned long long)n_done);
+  BWD_STAMP(5, (unsigned long long)n_steps_done);
+  (void)n_done; (void)n_steps_done;
   // ---- flush the tiles this wave owns into the block's slab row (parameter layout)
   float* slab = a.slab + (size_t)slab_row * C::P + C::OFF_ODE;
   float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
@@ -739,6 +773,7 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
       else if (ui == M::W) b3[uh] = G3[0][0][r];
     }
   }
+  BWD_STAMP(3, wall_clock64());
 }
 
 
@@ -765,6 +800,9 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
   const int T = (int)a.base_s[a.K + 2];
   const bool save = a.save_traj != 0;   // wave-uniform: a training forward stores checkpoints
                                          // and activations, an evaluation forward nothing
+  // (the backward's tile queue starts from zero: its last block clears it again, this covers the
+  // very first launch on a fresh workspace)
+  if (save && blockIdx.x == 0 && threadIdx.x == 0) { a.tile_q[0] = 0; a.tile_q[1] = 0; a.tile_q[2] = 0; }
   if ((int)blockIdx.x < ns) {
     if (save) ode_fwd_split<C, DROP, false, true>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
     else ode_fwd_split<C, DROP, false, false>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
@@ -788,6 +826,23 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   const int T = (int)a.base_s[a.K + 1];
   // both roles read the forward's step records (njode_ode2.h): the mixed kernels only run with
   // a saved forward, which always has them
+#ifdef NJ_BWD_STAMPS
+  BWD_STAMP(0, wall_clock64());
+  BWD_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4 /* HW_ID */) |
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20 /* XCC_ID */) << 32));
+  BWD_STAMP(7, (unsigned long long)((int)blockIdx.x < ns ? 1 : 0) | ((unsigned long long)T << 8) |
+                   ((unsigned long long)gridDim.x << 32));
+#endif
+  if (a.tile_q_on) {   // (uniform) tile queue, persistent blocks
+    if ((int)blockIdx.x < ns) {
+      ode3_bwd_split<C, DROP, true>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x, n_tiles);
+    } else {
+      const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
+      ode3_bwd_single<C, DROP, true>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
+    }
+    queue_block_done(a.tile_q, gridDim.x);
+    return;
+  }
   if ((int)blockIdx.x < ns) {
     ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
   } else {

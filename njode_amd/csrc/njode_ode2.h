@@ -507,11 +507,20 @@ template <class C> struct OdeLdsFragsT {
   NJ_DEV float e3(int q, int de) const { return cur[(M::B3 - M::NFWD + ET * M::QH + q) * 64 + de]; }
   NJ_DEV float e2(int q, int de) const { return cur[(M::B2 - M::NFWD + ET * M::QW + q) * 64 + de]; }
 };
+// image layout of the one-wave backward's weight-gradient products (njode_mfma.h)
+#ifndef NJ_IMG_SWZ
+#define NJ_IMG_SWZ 0
+#endif
+#if NJ_IMG_SWZ
+using BwdIL = ImgSwz;
+#else
+using BwdIL = ImgPad;
+#endif
 template <class C> struct OdeBwdActLds {
   using M = MF<C>;
   static constexpr int NG = M::MTH * ((M::W + 1 + 15) / 16) + M::MT1 * ((M::W + 1 + 15) / 16) +
                             M::MT1 * ((M::IN0 + 1 + 15) / 16);
-  static constexpr int BODY = 4 * 2 * IMG_FLOATS + OdeLdsFragsT<C>::NVEC * 64;
+  static constexpr int BODY = 4 * 2 * BwdIL::FLOATS + OdeLdsFragsT<C>::NVEC * 64;
   static constexpr int RED = 3 * NG * 64 * 4;      // the block's final tile reduction
   static constexpr int FLOATS = BODY > RED ? BODY : RED;
 };
@@ -643,7 +652,49 @@ NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<
     }
 }
 
-template <class C, bool DROP>
+// ---- tile queue (round 5) --------------------------------------------------------------------
+// The backward's gradient accumulators persist across the tiles of a worker, so its blocks cannot
+// be handed out by the dispatcher as the forward's are: rounds 2-4 gave every worker its tiles
+// statically (snake order over 1 024 blocks, two per CU resident: the second half of the blocks
+// starts as first-half blocks retire, each with a prologue and a flush of its own, and whatever a
+// SIMD loses to its neighbours shows as idle time at the end of the launch,
+// profiles/r05_bwd_fixed_costs.txt).  Now the launch is exactly the resident blocks and every
+// worker pops the next tile -- longest first, the tiles are sorted -- from a counter in the
+// workspace: KArgs::tile_q[0] for the tiles [0, T) of the four-wave role, [1] for the bulk
+// [T, n_tiles), [2] counts finished blocks (the last one clears all three for the next launch;
+// the saving forward clears them once, too).  The pop for the NEXT tile is issued when a tile
+// starts, so its round trip to L2 hides behind the sweep.  Which tiles meet in one accumulator now
+// depends on timing: gradients agree between runs to fp32 summation order, not bitwise;
+// NJODE_BWD_QUEUE=0 restores the static rounds.
+NJ_DEV int queue_pop(int* q) {          // wave-uniform result; one atomic per wave
+  int t = 0;
+  if ((threadIdx.x & 63) == 0) t = atomicAdd(q, 1);
+  return __builtin_amdgcn_readfirstlane(t);
+}
+NJ_DEV void queue_block_done(int* tile_q, int n_blocks) {   // call once per block, all threads
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(tile_q + 2, 1) == n_blocks - 1) {
+      tile_q[0] = 0;
+      tile_q[1] = 0;
+      tile_q[2] = 0;
+      __threadfence();
+    }
+  }
+}
+#ifdef NJ_BWD_STAMPS
+// diagnostic build (tools/ubench/bwd_stamps.sh): per wave of k_ode_bwd_mixed the 100 MHz wall
+// clock at kernel entry, after the prologue, after the last tile, after the flush; tiles and
+// Euler steps done; hardware id; role
+__device__ unsigned long long g_bwd_stamps[8192 * 8];
+#define BWD_STAMP(slot, val) \
+  do { if ((threadIdx.x & 63) == 0) g_bwd_stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = (val); } while (0)
+#else
+#define BWD_STAMP(slot, val) do {} while (0)
+#endif
+
+template <class C, bool DROP, bool QUEUE = false>
 NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, int tile0, int tile1,
                             int slab_row) {
   using M = MF<C>;
@@ -652,10 +703,11 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   constexpr int NT1 = (M::W + 1 + 15) / 16;     // column tiles of [a, 1]
   constexpr int NT0 = (M::IN0 + 1 + 15) / 16;   // column tiles of [in0, 1]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  lfp img_d = lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
-  lfp fimg = lds_raw + 4 * 2 * IMG_FLOATS;
+  using IL = BwdIL;
+  lfp img_d = lds_raw + wv * 2 * IL::FLOATS, img_a = img_d + IL::FLOATS;
+  lfp fimg = lds_raw + 4 * 2 * IL::FLOATS;
   FR::stage(fimg, a.frag2, threadIdx.x, 256);
-  for (int i = threadIdx.x; i < 4 * 2 * IMG_FLOATS; i += 256) lds_raw[i] = 0.0f;
+  for (int i = threadIdx.x; i < 4 * 2 * IL::FLOATS; i += 256) lds_raw[i] = 0.0f;
   __syncthreads();
   FR F;
   F.init(fimg, lane);
@@ -683,9 +735,19 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   }
   float* const trash = a.trash + threadIdx.x * C::H;
   const int n_tiles = tile1 - tile0;
-  for (int round = 0; round * n_waves < n_tiles; ++round) {
-    const int rel = snake_tile(round, wave, n_waves);
-    if (rel >= n_tiles) continue;
+  BWD_STAMP(1, wall_clock64());
+  int q_next = QUEUE ? queue_pop(a.tile_q + 1) : 0;
+  int n_done = 0, n_steps_done = 0;
+  for (int round = 0; QUEUE || round * n_waves < n_tiles; ++round) {
+    int rel;
+    if constexpr (QUEUE) {
+      rel = q_next;
+      if (rel >= n_tiles) break;
+      q_next = queue_pop(a.tile_q + 1);   // (for the next round: in flight during this tile)
+    } else {
+      rel = snake_tile(round, wave, n_waves);
+      if (rel >= n_tiles) continue;
+    }
     const int tile = tile0 + rel;
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
@@ -700,6 +762,8 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     }
     // (uniform: scalar step loop, base16_s[s] a scalar load)
     const int nmax = BWD_ABL(64) ? 0 : uniform(wave_max(it.n));
+    ++n_done;
+    n_steps_done += nmax;
     // The record of the NEXT step (s - 1) is loaded INTO the registers of the current one as
     // soon as those are dead (a2 and h after delta2, a1 after delta1: no second register set,
     // no copies, waits spread over the step).  Loads are unconditional (step 0 reloads itself)
@@ -735,11 +799,11 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
       for (int q = 0; q < M::QH; ++q) d3[q] = dt * lam[q];
       if (!BWD_ABL(16)) {
-        img_write<M::QH>(img_d, d3, g, c);
-        img_write<M::Q1>(img_a, a2, g, c);
+        img_write<M::QH, IL>(img_d, d3, g, c);
+        img_write<M::Q1, IL>(img_a, a2, g, c);
       }
       if (!BWD_ABL(4)) wave_lds_sync();
-      if (!BWD_ABL(1)) dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
+      if (!BWD_ABL(1)) dw_accumulate<M::MTH, NT1, IL>(img_d, img_a, G3, g, c);
       f32x4 acc[M::MT1];
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
@@ -763,13 +827,13 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 
       // ---- layer 2
       if (!BWD_ABL(16)) {
-        img_write<M::QW>(img_d, d2, g, c);
-        img_write<M::Q1>(img_a, a1, g, c);
+        img_write<M::QW, IL>(img_d, d2, g, c);
+        img_write<M::Q1, IL>(img_a, a1, g, c);
       }
       if (!BWD_ABL(4)) wave_lds_sync();
       if (!BWD_ABL(1)) {
-        if constexpr (ER != 0) dw_accumulate_edge<E2::MT>(img_d, img_a, G2, GM, GN, lane, g, c);
-        else dw_accumulate<E2::MT, E2::NT>(img_d, img_a, G2, g, c);
+        if constexpr (ER != 0) dw_accumulate_edge<E2::MT, IL>(img_d, img_a, G2, GM, GN, lane, g, c);
+        else dw_accumulate<E2::MT, E2::NT, IL>(img_d, img_a, G2, g, c);
       }
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
@@ -793,11 +857,11 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 
       // ---- layer 1
       if (!BWD_ABL(16)) {
-        img_write<M::QW>(img_d, d1, g, c);
-        img_write<M::Q0>(img_a, b0, g, c);
+        img_write<M::QW, IL>(img_d, d1, g, c);
+        img_write<M::Q0, IL>(img_a, b0, g, c);
       }
       if (!BWD_ABL(4)) wave_lds_sync();
-      if (!BWD_ABL(1)) dw_accumulate<M::MT1, NT0>(img_d, img_a, G1, g, c);
+      if (!BWD_ABL(1)) dw_accumulate<M::MT1, NT0, IL>(img_d, img_a, G1, g, c);
       f32x4 acch[M::MTH];
 #pragma unroll
       for (int mt = 0; mt < M::MTH; ++mt) {
@@ -831,8 +895,13 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     }
   }
 
+  BWD_STAMP(2, wall_clock64());
+  BWD_STAMP(4, (unsigned long long)n_done);
+  BWD_STAMP(5, (unsigned long long)n_steps_done);
+  (void)n_done; (void)n_steps_done;
   if (BWD_ABL(128)) return;
   ode3_flush<C, DROP>(a, lds_raw, G3, G2, GM, GN, G1, slab_row);
+  BWD_STAMP(3, wall_clock64());
 }
 
 

@@ -213,24 +213,38 @@ class _Plan:
             pool.append(buf)
 
 
+_HT_GRAD_MSG = ('njode_amd: a gradient with respect to hT was requested.  The HIP backward '
+                '(njode_backward_f32) differentiates the LOSS only -- the reference returns hT inside '
+                'its autograd graph (models.py:414-518), this build does not propagate through it and '
+                'refuses instead of returning a gradient that silently ignores the hT term.  Use the '
+                'loss alone, or hT.detach().')
+
+
 class _NJODEFunction(torch.autograd.Function):
-    """loss = F(params); backward = exact discrete adjoint (njode_backward_f32)."""
+    """(loss, hT) = F(params); backward = exact discrete adjoint of the LOSS (njode_backward_f32).
+    hT is returned through the node so that a loss which touches it fails loudly (_HT_GRAD_MSG)
+    instead of being differentiated as if hT were a constant."""
 
     @staticmethod
-    def forward(ctx, model, call, loss, *params):
+    def forward(ctx, model, call, loss, hT, *params):
         ctx.model = model
         ctx.call = call
-        return loss.clone()
+        ctx.set_materialize_grads(False)
+        return loss.clone(), hT.view_as(hT)
 
     @staticmethod
-    def backward(ctx, grad_loss):
+    def backward(ctx, grad_loss, grad_hT):
+        if grad_hT is not None:
+            raise NotImplementedError(_HT_GRAD_MSG)
         model, call = ctx.model, ctx.call
         grad_flat = torch.empty_like(model._flat)
+        if grad_loss is None:
+            grad_loss = torch.zeros(1, device=model._flat.device)
         g = grad_loss.to(device=model._flat.device, dtype=torch.float32).reshape(1).contiguous()
         model._run_backward(call, g, grad_flat)
         model._release_ws(call)
         grads = [grad_flat[off:off + n].view(shape) for (off, n, shape) in model._param_slices]
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 # =====================================================================================
@@ -743,7 +757,8 @@ class NJODE(torch.nn.Module):
             raise
         if want_grad:
             self._ensure_flat()
-            loss_out = _NJODEFunction.apply(self, call, loss, *self._flat_params).reshape(())
+            loss_out, hT = _NJODEFunction.apply(self, call, loss, hT, *self._flat_params)
+            loss_out = loss_out.reshape(())
         else:
             self._release_ws(call)
             loss_out = loss.reshape(()) if get_loss else 0

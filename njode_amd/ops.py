@@ -93,17 +93,25 @@ def _setup_context(ctx, inputs, output):
     ctx.model_id = inputs[10]
     ctx.n_params = len(inputs[0])
     ctx.call_id = int(output[2])
+    ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not zeros
     if ctx.call_id:
         weakref.finalize(ctx, _drop_call, ctx.call_id)
 
 
 def _backward(ctx, grad_hT, grad_loss, grad_id):
+    if grad_hT is not None:
+        # the library differentiates the loss only; a loss that touches hT must not get a
+        # gradient that silently drops that term (reference: hT is inside the graph)
+        from .models import _HT_GRAD_MSG
+        raise NotImplementedError(_HT_GRAD_MSG)
     model = _MODELS[ctx.model_id]
     call = _CALLS.pop(ctx.call_id, None)
     if call is None:
         raise RuntimeError('njode_amd::forward was not run with save_bwd=True, or its backward '
                            'already ran (a second backward is not supported)')
     grad_flat = torch.empty_like(model._flat)
+    if grad_loss is None:
+        grad_loss = torch.zeros(1, device=model._flat.device)
     g = grad_loss.to(device=model._flat.device, dtype=torch.float32).reshape(1).contiguous()
     model._run_backward(call, g, grad_flat)
     model._release_ws(call)

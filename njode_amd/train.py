@@ -202,8 +202,6 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
         nxt = prepare(0) if n_steps > 0 else None
         for s in range(n_steps):
             idx, lo, mine, d = nxt
-            if d.get('ready') is not None:
-                torch.cuda.current_stream().wait_event(d['ready'])
             # one batch ahead: the next batch is collated now, and (fused loop) its execution
             # plan is built on a helper stream beside this step (NJODE.prefetch_plan)
             nxt = prepare(s + 1) if s + 1 < n_steps else None
@@ -216,8 +214,6 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             if plan_ahead and fused and n_next >= max(plan_ahead_min, 1) and \
                     (n_next <= 512 or n_next >= 4096):
                 dn = nxt[3]
-                if dn.get('ready') is not None:
-                    torch.cuda.current_stream().wait_event(dn['ready'])
                 model.prefetch_plan(dn['times'], dn['time_ptr'], dn['X'], dn['obs_idx'], delta_t, T,
                                     dn['start_X'], dn['n_obs_ot'], need_hT=False)
             parallel.configure_model(model, len(idx), lo)

@@ -612,8 +612,53 @@ def g11():
     save('g8_climate_eval', cfg, arrays)
 
 
+def g13():
+    """float64 TRUTH for the masked fixtures (round 5).  The reference's own model, the stored
+    parameters and inputs of g5_masked / g5_full / g5_w200, evaluated in float64
+    (`model.double()`, inputs `.double()`): the times the reference feeds its networks as float32
+    tensors (models.py:419 `tau`, :187 `torch.tensor([t])`) stay float32 -- they are inputs that
+    both fp32 implementations see -- and every product, tanh and sum behind them is float64.
+    tests/test_hip_f64_truth.py compares err(HIP, truth) with err(reference fp32, truth)."""
+    arrays = {}
+    for name in ('g5_masked', 'g5_full', 'g5_w200'):
+        z = np.load(os.path.join(HERE, name + '.npz'), allow_pickle=False)
+        cfg = json.loads(str(z['cfg_json']))
+        for k in ('ode_nn', 'readout_nn', 'enc_nn'):
+            if cfg[k] is not None:
+                cfg[k] = tuple(tuple(l) for l in cfg[k])
+        model = build(cfg)
+        sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('sd/')}
+        model.load_state_dict(sd)
+        model = model.double()
+        b = {'times': z['times'], 'time_ptr': z['time_ptr'].tolist(),
+             'X': torch.from_numpy(z['X']).double(), 'obs_idx': torch.from_numpy(z['obs_idx']),
+             'start_X': torch.from_numpy(z['start_X']).double(),
+             'n_obs_ot': torch.from_numpy(z['n_obs_ot'])}
+        M = torch.from_numpy(z['M']).double()
+        dt, T = float(z['delta_t']), float(z['T'])
+        out = eval_outputs(model, b, dt, T, M=M)
+        assert np.array_equal(out['path_t'], z['path_t'])
+        if 'path_rows' in z.files:
+            out['path_y'] = out['path_y'][z['path_rows']]
+        arrays[name + '/path_y'] = out['path_y']
+        arrays[name + '/hT'] = out['hT']
+        arrays[name + '/loss'] = out['loss']
+        g = grad_outputs(model, b, dt, T, M=M)
+        arrays[name + '/train_loss'] = g['train_loss']
+        arrays[name + '/train_hT'] = g['train_hT']
+        for k, v in g.items():
+            if k.startswith('grad/'):
+                arrays[name + '/' + k] = v
+        e32 = np.abs(z['path_y'].astype(np.float64) - out['path_y']).max()
+        print('    {}: max |reference fp32 - float64| on path_y = {:.3e}, loss rel {:.2e}'.format(
+            name, e32, abs(float(z['loss']) - float(out['loss'])) / abs(float(out['loss']))))
+    path = os.path.join(HERE, 'g13_f64_truth.npz')
+    np.savez_compressed(path, **arrays)
+    print('{:28s} {:8.1f} KB'.format('g13_f64_truth', os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13']
     for name in which:
         globals()[name]()

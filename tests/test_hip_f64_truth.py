@@ -1,0 +1,94 @@
+"""float64 truth test of the masked fixtures (round 5).
+
+tests/golden/g13_f64_truth.npz holds the REFERENCE's model evaluated in float64 on the stored
+parameters and inputs of g5_masked / g5_full / g5_w200 (make_golden.py:g13).  Masked mode feeds
+every prediction back as an input (models.py:465-467, 483-484), so two correct fp32 evaluations
+drift apart by more than a plain 1e-5; what a tolerance against the reference's fp32 output
+cannot tell is WHICH of the two is off.  Here both are measured against the float64 result:
+
+    err(HIP fp32, f64)  <=  2 x err(reference fp32, f64)        (max-abs and L2)
+
+on the prediction path, hT, the loss and every gradient tensor -- i.e. the HIP result is no
+further from the truth than the reference itself is (factor 2: two fp32 evaluations of the same
+recursion round differently, neither is privileged).  The CPU half (not gpu) checks the fixture
+against the fp32 goldens, so the truth cannot silently be something else.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN_DIR, Golden
+
+CASES = ['g5_masked', 'g5_full', 'g5_w200']
+FACTOR = 2.0
+
+
+def _truth():
+    import os
+    return np.load(os.path.join(GOLDEN_DIR, 'g13_f64_truth.npz'), allow_pickle=False)
+
+
+def _errs(x, truth):
+    d = np.asarray(x, dtype=np.float64) - np.asarray(truth, dtype=np.float64)
+    return float(np.abs(d).max()), float(np.linalg.norm(d))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_truth_fixture_is_the_f64_twin_of_the_fp32_golden(name):
+    """CPU: same shapes, float64, and the reference's fp32 output sits within fp32 drift of it."""
+    g, t = Golden(name), _truth()
+    y32, y64 = g['path_y'], t[name + '/path_y']
+    assert y64.dtype == np.float64 and y64.shape == y32.shape
+    e_max, _ = _errs(y32, y64)
+    assert 0.0 < e_max < 1e-3 * max(1.0, float(np.abs(y64).max()))
+    assert float(g['loss']) == pytest.approx(float(t[name + '/loss']), rel=1e-5)
+    for k, ref in g.group('grad').items():
+        g64 = t[name + '/grad/' + k]
+        assert g64.dtype == np.float64 and g64.shape == ref.shape
+        assert np.linalg.norm(ref - g64) <= 1e-3 * np.linalg.norm(g64) + 1e-12, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_hip_is_as_close_to_float64_as_the_reference_is(name):
+    from hip_util import grads_by_name, hip_forward, hip_model
+    g, t = Golden(name), _truth()
+    m = hip_model(g.cfg, g.state_dict()).eval()
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = hip_forward(
+            m, g.batch(), g.delta_t, g.T, return_path=True, get_loss=True, until_T=True)
+    rows = g['path_rows'] if 'path_rows' in g else slice(None)
+    report = {}
+    for key, got, ref32 in (('path_y', path_y.cpu().numpy()[rows], g['path_y']),
+                            ('hT', hT.cpu().numpy(), g['hT'])):
+        truth = t[name + '/' + key]
+        h_max, h_l2 = _errs(got, truth)
+        r_max, r_l2 = _errs(ref32, truth)
+        report[key] = (h_max, r_max, h_l2, r_l2)
+        assert h_max <= FACTOR * r_max, (key, 'max', h_max, r_max)
+        assert h_l2 <= FACTOR * r_l2, (key, 'l2', h_l2, r_l2)
+    l64 = float(t[name + '/loss'])
+    # (the loss is one fp32 number: its error against float64 is a handful of ulps for either side;
+    # a floor of 4 ulp keeps the comparison from being a coin toss)
+    floor = 4 * np.finfo(np.float32).eps * abs(l64)
+    assert abs(float(loss) - l64) <= FACTOR * abs(float(g['loss']) - l64) + floor
+    # gradients
+    m.train()
+    _, tl = hip_forward(m, g.batch(), g.delta_t, g.T)
+    tl.backward()
+    got = grads_by_name(m)
+    tl64 = float(t[name + '/train_loss'])
+    assert abs(float(tl) - tl64) <= FACTOR * abs(float(g['train_loss']) - tl64) + 4 * np.finfo(np.float32).eps * abs(tl64)
+    worst = 0.0
+    for k, ref32 in g.group('grad').items():
+        truth = t[name + '/grad/' + k]
+        h_max, h_l2 = _errs(got[k], truth)
+        r_max, r_l2 = _errs(ref32, truth)
+        # per tensor, with a floor of one fp32 ulp of the tensor's largest entry (tiny bias
+        # gradients: either side is then exact to rounding)
+        ulp = np.finfo(np.float32).eps * float(np.abs(truth).max())
+        assert h_l2 <= FACTOR * r_l2 + ulp * np.sqrt(truth.size), (k, 'l2', h_l2, r_l2)
+        assert h_max <= FACTOR * r_max + 4 * ulp, (k, 'max', h_max, r_max)
+        worst = max(worst, h_l2 / max(r_l2, 1e-300))
+    print('{}: path_y max err HIP {:.3e} / reference {:.3e}; L2 {:.3e} / {:.3e}; worst gradient '
+          'L2 ratio {:.2f}'.format(name, *report['path_y'], worst))

@@ -55,3 +55,28 @@ def test_second_backward_through_the_operator_raises():
     loss.backward(retain_graph=True)
     with pytest.raises(RuntimeError):
         loss.backward()
+
+
+@pytest.mark.parametrize('use_op', [False, True])
+def test_gradient_through_hT_is_refused_not_dropped(use_op):
+    """The reference returns hT inside its autograd graph (models.py:414-518); the library
+    differentiates the loss only.  A loss that touches hT must raise on both routes -- round 4's
+    custom-op route received grad_hT and ignored it -- while the loss alone still trains."""
+    cfg = demo_cfg()
+    cfg['options'] = dict(cfg.get('options', {}), torch_library_op=use_op, device_outputs=True)
+    torch.manual_seed(0)
+    m = models.NJODE(**cfg).cuda().train()
+    b, meta = bs_batch(16, seed=3)
+    b = to_dev(b)
+    args = (b['times'], b['time_ptr'], b['X'], b['obs_idx'], meta['dt'], meta['maturity'],
+            b['start_X'], b['n_obs_ot'])
+    hT, loss = m(*args)
+    assert hT.requires_grad                       # part of the graph, as in the reference
+    with pytest.raises(NotImplementedError, match='hT'):
+        (loss + hT.sum()).backward()
+    hT, loss = m(*args)
+    with pytest.raises(NotImplementedError, match='hT'):
+        hT.sum().backward()
+    hT, loss = m(*args)
+    (2.0 * loss + hT.detach().sum()).backward()   # detached: fine
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

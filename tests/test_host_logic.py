@@ -342,3 +342,44 @@ def test_self_spawned_ranks_are_killed_after_the_rank_timeout():
     assert p.returncode == 124, (p.returncode, p.stderr[-2000:])
     assert 'process group killed' in p.stderr
     assert time.time() - t0 < 60
+
+
+def test_sigterm_to_the_spawning_parent_takes_the_ranks_down():
+    """the ranks live in a session of their own, so a SIGTERM to bench.py must be
+    passed on (kill the group, exit non-zero) -- not leave torchrun and N ranks orphaned."""
+    import signal
+    import subprocess
+    import time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NJODE_BENCH_SHARE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    # a launcher that would run for minutes: the parent sits in child.wait()
+    p = subprocess.Popen([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '1',
+                          '--warmup', '0', '--rank-timeout', '600'], env=env, cwd=repo,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # find the launcher child (torch.distributed.run, a session leader) before signalling
+    child_pid = None
+    for _ in range(100):
+        time.sleep(0.1)
+        out = subprocess.run(['ps', '-o', 'pid=,sid=,args=', '--ppid', str(p.pid)], stdout=subprocess.PIPE,
+                             text=True).stdout
+        for line in out.splitlines():
+            f = line.split(None, 2)
+            if len(f) == 3 and 'torch.distributed.run' in f[2]:
+                child_pid = int(f[0])
+        if child_pid or p.poll() is not None:
+            break
+    if p.poll() is not None:
+        pytest.skip('the ranks finished before they could be signalled')
+    assert child_pid is not None
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=60)
+    assert rc == 128 + signal.SIGTERM
+    for _ in range(100):                      # the launcher's whole session is gone
+        alive = subprocess.run(['ps', '-o', 'pid=', '-s', str(child_pid)], stdout=subprocess.PIPE,
+                               text=True).stdout.split()
+        if not alive:
+            break
+        time.sleep(0.1)
+    assert not alive, alive

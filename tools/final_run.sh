@@ -4,8 +4,14 @@
 #   1. the GPU test suite; 2. rocprofv3 stats + PMC passes of `python3 bench.py` -> <R>_final_*;
 #   3. the PMC summary goes to profiles/ FIRST, so that 4. `python bench.py` (the driver's command)
 #   finds the counters of this very library (roofline.traffic); 5. timelines and side benches.
-R=${1:-r04}
+R=${1:-r05}
+set -o pipefail
+# (the suite's verdict travels with the artifacts; profiles of a library whose suite is red are not
+# evidence: abort before they are produced)
 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+rc=$?
+echo "pytest -m gpu rc=$rc" > gpurun_out/${R}_final_pytest_rc.txt
+if [ $rc -ne 0 ]; then echo "GPU suite failed (rc $rc): no profiles taken"; exit $rc; fi
 bash tools/profile_recipe.sh ${R}_final > gpurun_out/${R}_final_recipe.out 2>&1
 cp gpurun_out/${R}_final_pmc_summary.json profiles/${R}_final_pmc_summary.json
 python bench.py > gpurun_out/${R}_final_bench.json 2> gpurun_out/${R}_final_bench.err
