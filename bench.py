@@ -266,6 +266,49 @@ def autograd_route_ms(dev, dt, T, step_args, dropout, steps):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
+def strong_scaling_20k(model, opt, dev, world, rank, steps, warmup, prefetch):
+    """BASELINE's own 20 000-path batch SHARED by the N ranks (20 000 / N paths each, loss over the
+    global batch, the same one all-reduce + fused Adam per step), timed like the headline (barrier
+    + synchronize on both sides, max over ranks): the strong-scaling reading of `paths/sec on 20k
+    Black-Scholes at 1/2/4/8 GPUs`, next to the weak-scaling headline, so that a SCALE record
+    cannot be read two ways.  An extra outside the timed region of `value`."""
+    from njode_amd import parallel
+    G = 20000
+    lo, hi = parallel.shard_range(G, world, rank)
+    b, meta = make_global_slice(lo, hi)
+    model.dp_global_batch, model.dp_path_offset = G, lo
+    model._plans.clear()
+    args = (b['times'], b['time_ptr'], b['X'].to(dev), b['obs_idx'].to(dev, torch.int32), meta['dt'],
+            meta['maturity'], b['start_X'].to(dev), b['n_obs_ot'].to(dev, torch.int32))
+
+    def one():
+        if prefetch:
+            model.prefetch_plan(*args, need_hT=False)
+        model.loss_and_grad(*args)
+        opt.step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if prefetch:
+        model.prefetch_plan(*args, need_hT=False)
+    for _ in range(warmup):
+        one()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    sync()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    model._plans.clear()
+    return 1e3 * float(t) / steps, hi - lo
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -387,6 +430,8 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-small-batch', action='store_true')
     ap.add_argument('--no-autograd-route', action='store_true')
+    ap.add_argument('--no-strong-20k', action='store_true',
+                    help='N > 1, weak scaling: skip the extra strong-scaling pass over the 20 000-path batch')
     ap.add_argument('--dump-params', default='',
                     help='rank 0 saves the flat parameter vector after the timed steps (.npy)')
     ap.add_argument('--no-plan-prefetch', action='store_true',
@@ -524,6 +569,10 @@ def main():
     if args.dump_params and rank == 0:
         np.save(args.dump_params, flat.cpu().numpy())
 
+    strong20 = None
+    if distributed and not strong and not args.no_strong_20k:
+        strong20 = strong_scaling_20k(model, opt, dev, world, rank, args.steps, min(args.warmup, 10), prefetch)
+
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = global_batch * args.steps / elapsed
@@ -553,6 +602,12 @@ def main():
             out['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 5)
             out['allreduce_floats'] = int(model.grad_bucket().numel())   # gradient + the loss slot
             out['ms_per_step_by_rank'] = [round(1e3 * x / args.steps, 4) for x in per_rank]
+            if strong20 is not None:
+                out['strong_20k_ms'] = round(strong20[0], 4)
+                out['strong_20k_paths_per_s'] = round(20000 / (strong20[0] * 1e-3), 1)
+                out['strong_20k_note'] = ('extra, outside `value`: BASELINE\'s 20 000-path batch shared by the {} '
+                                          'ranks ({} paths on rank 0), same all-reduce + Adam per step; `value` '
+                                          'is WEAK scaling ({} paths per rank)'.format(world, strong20[1], B))
         if kern:
             per = {k: round(v[1] / max(v[0], 1), 5) for k, v in kern.items()}
             out['kernel_ms'] = per

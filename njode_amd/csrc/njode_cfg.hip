@@ -4,6 +4,7 @@
 //   -DNJ_ID=.. -DNJ_D=.. -DNJ_H=.. -DNJ_DO=.. -DNJ_NH=.. -DNJ_W=.. -DNJ_ACT=..
 //   -DNJ_MASKED=.. -DNJ_CURT=.. -DNJ_RES=.. -DNJ_PART=..
 #include <cstdlib>
+#include <cstring>
 
 #include "njode_host.h"
 
@@ -163,7 +164,15 @@ static void launch_mfma_fwd(const KArgs& a, bool split, hipStream_t st) {
     const int n_tiles = cdiv(TAIL ? a.B : a.n_obs, 16);
     if constexpr (HAS_SPLIT) {
       if (split) {
-        if constexpr (TAIL) k_ode_fwd_split<CC, DROP, true><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, st>>>(a);
+        if constexpr (TAIL) {
+          // (small plans: the four-wave form, whose latency per tile IS the kernel time there;
+          // NJODE_TAILS=split keeps it for every plan: A/B)
+          static const bool tails_split = getenv("NJODE_TAILS") && strcmp(getenv("NJODE_TAILS"), "split") == 0;
+          if (n_tiles <= 768 || tails_split)
+            k_ode_fwd_split<CC, DROP, true><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, st>>>(a);
+          else
+            k_ode_fwd_tails<CC, DROP><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
+        }
         else k_ode_fwd_mixed<CC, DROP><<<a.n_blocks_fwd, 256, 0, st>>>(a);
         return;
       }

@@ -68,24 +68,37 @@ template <int N> NJ_DEV void pin(float (&v)[N]) {
 // (cancellation against 1 for small |x|), fine for the unmasked path.  Masked models
 // feed their own predictions back as inputs (self-imputation, models.py:465-467),
 // which amplifies rounding differences step after step, so those translation units are
-// built with NJ_ACC_TANH=1: |x| < 0.3 uses the odd Taylor polynomial to x^11
-// (truncation < 6e-10), keeping the error at a few ulp of the result.
+// built with NJ_ACC_TANH=1 (tanh_accurate below).
 #ifndef NJ_ACC_TANH
 #define NJ_ACC_TANH 0
 #endif
-NJ_DEV float tanh_f(float x) {
+// Round 5: the float64 truth test (tests/test_hip_f64_truth.py) put a number on it -- with the
+// round-1 form (odd Taylor polynomial below |x| = 0.3, the exp form above: up to 3 ulp around
+// 0.3 - 0.8 even with an exact exp2, where 1 - 2 r cancels) the masked prediction path ended
+// 3.2x as far from the float64 result as the reference's own fp32 run; restating just this tanh
+// in the CPU oracle reproduces the factor, a k-ordered summation does not.  Now, for |x| < 1, the
+// [7/6] Pade approximant of Lambert's continued fraction written as a CORRECTION of x,
+//   tanh x = x - x q,   q = x^2 (45045 + 2772 x^2 + 27 x^4) / (135135 + 62370 x^2 + 3150 x^4 + 28 x^6)
+// (truncation < 1e-9 there; q < 0.33, so the error of the division enters scaled down), and the
+// exp form above 1, where 2 r < 0.24: <= 1.3 ulp overall with exact exp2 / rcp (the round-1 form:
+// 2.8), at the same instruction count.
+NJ_DEV float tanh_accurate(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-#if NJ_ACC_TANH
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
   const float x2 = x * x;
-  float p = fmaf(x2, -8.8632355299021965e-3f, 2.1869488536155203e-2f);
-  p = fmaf(x2, p, -5.3968253968253971e-2f);
-  p = fmaf(x2, p, 1.3333333333333333e-1f);
-  p = fmaf(x2, p, -3.3333333333333331e-1f);
-  const float s = fmaf(x * x2, p, x);
-  t = fabsf(x) < 0.3f ? s : t;
+  const float m = fmaf(fmaf(x2, 27.0f, 2772.0f), x2, 45045.0f);
+  const float d = fmaf(fmaf(fmaf(x2, 28.0f, 3150.0f), x2, 62370.0f), x2, 135135.0f);
+  const float q = (x2 * m) * __builtin_amdgcn_rcpf(d);
+  const float s = fmaf(-x, q, x);
+  return fabsf(x) < 1.0f ? s : t;
+}
+NJ_DEV float tanh_f(float x) {
+#if NJ_ACC_TANH
+  return tanh_accurate(x);
+#else
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 #endif
-  return t;
 }
 template <int ACT> NJ_DEV float act_f(float z) {
   if constexpr (ACT == ACT_TANH) return tanh_f(z);

@@ -170,17 +170,7 @@ __host__ __device__ inline int gen_lds_floats(int img_rows, int D, int H, int DO
   return 2 * img_rows * 16 + 2 * H * 16 + D * 16 + 5 * mx * 16 + 8 * 16 + 16;
 }
 
-NJ_DEV float tanh_acc(float x) {   // few-ulp tanh (njode_device.h, NJ_ACC_TANH form)
-  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  const float x2 = x * x;
-  float p = fmaf(x2, -8.8632355299021965e-3f, 2.1869488536155203e-2f);
-  p = fmaf(x2, p, -5.3968253968253971e-2f);
-  p = fmaf(x2, p, 1.3333333333333333e-1f);
-  p = fmaf(x2, p, -3.3333333333333331e-1f);
-  const float s = fmaf(x * x2, p, x);
-  return fabsf(x) < 0.3f ? s : t;
-}
+NJ_DEV float tanh_acc(float x) { return tanh_accurate(x); }   // (njode_device.h: <= ~1.3 ulp)
 NJ_DEV float act_rt(int act, float z) { return act == ACT_TANH ? tanh_acc(z) : fmaxf(z, 0.0f); }
 NJ_DEV float dact_rt(int act, float av) { return act == ACT_TANH ? 1.0f - av * av : (av > 0.0f ? 1.0f : 0.0f); }
 

@@ -119,9 +119,13 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
   if (!d) { *why = "null dims"; return false; }
   const int D = d->input_size, H = d->hidden_size, DO = d->output_size;
   if (D <= 0 || H <= 0 || DO <= 0 || D > 512 || H > 1024 || DO > 512) { *why = "sizes out of range"; return false; }
-  if (D != DO) { *why = "the loss compares X with the readout: input_size must equal output_size"; return false; }
   const bool masked = d->flags & NJODE_F_MASKED, curt = d->flags & NJODE_F_INPUT_CURRENT_T,
              res = d->flags & NJODE_F_RESIDUAL;
+  // (round 5) output_size != input_size: the reference builds a readout to any output_size
+  // (models.py:350-352); what compares X with the readout -- the loss, and the masked mode's
+  // self-imputation / prediction feed-back (models.py:465-467, 483-484) -- needs equal sizes, so
+  // such a model runs prediction calls only (get_loss = False; checked per call in prepare())
+  if (D != DO && masked) { *why = "masked mode feeds the readout back as the input: input_size must equal output_size"; return false; }
   GArgs& a = m.a;
   a.D = D; a.H = H; a.DO = DO;
   a.masked = masked; a.curt = curt;
@@ -156,7 +160,7 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
   a.rnn = (d->flags & NJODE_F_USE_RNN) ? 1 : 0;
   if (a.rnn) {
     // the GRU cell as ONE layer [x; h; 1] -> [r, z, W_in x + b_in, W_hn h + b_hn]  (njode_gen.h, gru_w)
-    if (masked) { *why = "use_rnn with masked data is not defined by the reference (models.py:353)"; return false; }
+    if (masked) { *why = "use_rnn with masked data is not built: the reference runs its GRU on the zero-filled X_obs (models.py:460) -- a known gap of this library"; return false; }
     if (4 * H > NJODE_GEN_MAX_WIDTH) { *why = "use_rnn: 4 x hidden_size exceeds the widest layer the kernels take"; return false; }
     GNet1& N = a.gru;
     N.nl = 1;
@@ -488,6 +492,9 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
     a.flags = (int*)(w + c.L.flags);
     a.rec_gru = a.rnn ? (float*)(w + c.L.rec_gru) : nullptr;
   }
+  if (c.m.a.D != c.m.a.DO && (call_flags & (NJODE_C_GET_LOSS | NJODE_C_SAVE_BWD)))
+    return fail(NJODE_E_BADARG, "the loss compares X with the readout: a model with input_size != output_size "
+                                "runs prediction calls only (get_loss = False)");
   a.want_loss = (call_flags & NJODE_C_GET_LOSS) ? 1 : 0;
   a.want_path = (call_flags & NJODE_C_RETURN_PATH) ? 1 : 0;
   const bool any_hidden = c.m.a.ode.nl > 1 || c.m.a.enc.nl > 1 || c.m.a.dec.nl > 1;

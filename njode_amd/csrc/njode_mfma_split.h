@@ -609,27 +609,36 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
   // (QUEUE: wave 0 pops -- one tile ahead, so the atomic's round trip hides behind the sweep -- and
   // hands the tile to the block through one LDS word)
   int __attribute__((address_space(3)))* qword = (int __attribute__((address_space(3)))*)(lds_raw + OdeBwdSplitLds<C>::FLOATS - 64);
-  int q_phase = 0;
-  auto pop = [&]() -> int {
+  // (QUEUE) wave 0 pops: first tile = the block's own index (static, no burst at launch), then
+  // tile_q[0] counts on from n_workers through [tile0, tile1), then tile_q[1] from the bulk's
+  // worker count through [tile1, n_all); the pop for the NEXT tile is issued, unwaited, when a
+  // tile's prologue is done and read one tile later (njode_ode2.h, queue_pop_issue)
+  const int n_bulk_workers = QUEUE ? ((int)gridDim.x - n_workers) * 4 : 0;
+  int q_phase = 0, q_raw = 0;
+  auto resolve = [&](int raw) -> int {          // tile of a returned pop; may need a second pop
     if (q_phase == 0) {
-      const int t = queue_pop(a.tile_q);
+      const int t = n_workers + queue_value(raw);
       if (t < n_tiles) return tile0 + t;
       q_phase = 1;
+      return tile1 + n_bulk_workers + queue_value(queue_pop_issue(a.tile_q + 1));
     }
-    return tile1 + queue_pop(a.tile_q + 1);
+    return tile1 + n_bulk_workers + queue_value(raw);
   };
   int q_next = 0;
-  if constexpr (QUEUE) { if (w == 0) q_next = pop(); }
+  if constexpr (QUEUE) {
+    if (worker < n_tiles) q_next = tile0 + worker;
+    else { q_phase = 1; if (w == 0) q_next = tile1 + n_bulk_workers + queue_value(queue_pop_issue(a.tile_q + 1)); }
+  }
   int n_done = 0, n_steps_done = 0;
   for (int round = 0; QUEUE || round * n_workers < n_tiles; ++round) {
     int tile;
     if constexpr (QUEUE) {
+      if (round > 0 && w == 0) q_next = resolve(q_raw);
       if (w == 0 && lane == 0) *qword = q_next;
       block_lds_barrier();
       tile = uniform(*qword);
       block_lds_barrier();
       if (tile >= n_all) break;
-      if (w == 0) q_next = pop();
     } else {
       const int rel = snake_tile(round, worker, n_workers);
       if (rel >= n_tiles) continue;
@@ -661,6 +670,7 @@ NJ_DEV void ode3_bwd_split(const KArgs& a, lfp lds_raw, int worker, int n_worker
     };
     if (nmax > 0) fetch(nmax - 1);
     vm_drain();
+    if constexpr (QUEUE) { if (w == 0) q_raw = queue_pop_issue(a.tile_q + (q_phase == 0 ? 0 : 1)); }
     for (int s = nmax - 1; s >= 0; --s) {
       float h[M::QH], a1u[4], a2u[4];
       nx.unpack(w, a1u, a2u, h);
@@ -785,6 +795,14 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_split(KArgs a) {
   const int n_items = TAIL ? a.B : a.n_obs;
   // (only launched for the tails: the items of a saving forward go through the mixed kernel)
   ode_fwd_split<C, DROP, TAIL, false>(a, (lfp)lds_raw, blockIdx.x, gridDim.x, 0, (n_items + 15) / 16);
+}
+
+// Tails of a LARGE plan (round 5): one wave per tile on the scaled fragments, like the bulk of
+// the mixed kernel -- the tails run BESIDE the items' forward on a busy chip, where the throughput
+// per SIMD counts, not the latency of one tile (the four-wave form above: ~20 % less per SIMD)
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64) k_ode_fwd_tails(KArgs a) {
+  ode2_fwd_single<C, DROP, true, false>(a, threadIdx.x, blockIdx.x, gridDim.x, 0, (a.B + 15) / 16);
 }
 
 // Mixed form.  Tiles are sorted by length; the split point T (k_split_point, on the device)

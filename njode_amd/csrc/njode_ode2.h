@@ -509,7 +509,7 @@ template <class C> struct OdeLdsFragsT {
 };
 // image layout of the one-wave backward's weight-gradient products (njode_mfma.h)
 #ifndef NJ_IMG_SWZ
-#define NJ_IMG_SWZ 0
+#define NJ_IMG_SWZ 1   // (round 5: conflict-free, k_ode_bwd_mixed -0.5 .. -0.9 %, profiles/r05_lds_conflicts.txt; 0: padded rows, A/B)
 #endif
 #if NJ_IMG_SWZ
 using BwdIL = ImgSwz;
@@ -521,7 +521,7 @@ template <class C> struct OdeBwdActLds {
   static constexpr int NG = M::MTH * ((M::W + 1 + 15) / 16) + M::MT1 * ((M::W + 1 + 15) / 16) +
                             M::MT1 * ((M::IN0 + 1 + 15) / 16);
   static constexpr int BODY = 4 * 2 * BwdIL::FLOATS + OdeLdsFragsT<C>::NVEC * 64;
-  static constexpr int RED = 3 * NG * 64 * 4;      // the block's final tile reduction
+  static constexpr int RED = 3 * NG * 64 * 4;      // the block's final tile reduction (upper bound: NG of the no-edge form)
   static constexpr int FLOATS = BODY > RED ? BODY : RED;
 };
 // (-DNJ_BWD_ABL=bits, tools/ubench/bwd_ablate.sh: parts of the Euler-step loop switched off for
@@ -666,11 +666,18 @@ NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<
 // starts, so its round trip to L2 hides behind the sweep.  Which tiles meet in one accumulator now
 // depends on timing: gradients agree between runs to fp32 summation order, not bitwise;
 // NJODE_BWD_QUEUE=0 restores the static rounds.
-NJ_DEV int queue_pop(int* q) {          // wave-uniform result; one atomic per wave
+// (the pop is issued WITHOUT a wait -- lane 0's register holds the counter's old value once the
+// atomic has returned; queue_value() reads it when the next tile starts, a whole tile later.
+// profiles/r05_bwd_fixed_costs.txt: waited for at once, the round trip of 1 920 waves popping one
+// address was 4.1 us per tile, and the burst at launch -- every wave popping its first tile at the
+// same instant -- is why the first tile of a worker is static: tile = worker index, pops count on
+// from the number of workers)
+NJ_DEV int queue_pop_issue(int* q) {
   int t = 0;
   if ((threadIdx.x & 63) == 0) t = atomicAdd(q, 1);
-  return __builtin_amdgcn_readfirstlane(t);
+  return t;
 }
+NJ_DEV int queue_value(int raw) { return __builtin_amdgcn_readfirstlane(raw); }
 NJ_DEV void queue_block_done(int* tile_q, int n_blocks) {   // call once per block, all threads
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -686,10 +693,11 @@ NJ_DEV void queue_block_done(int* tile_q, int n_blocks) {   // call once per blo
 #ifdef NJ_BWD_STAMPS
 // diagnostic build (tools/ubench/bwd_stamps.sh): per wave of k_ode_bwd_mixed the 100 MHz wall
 // clock at kernel entry, after the prologue, after the last tile, after the flush; tiles and
-// Euler steps done; hardware id; role
-__device__ unsigned long long g_bwd_stamps[8192 * 8];
+// Euler steps done; hardware id; role; [8] sum over tiles of (tile start -> first Euler step), [9] of
+// the step loops, [10] of the queue pops
+__device__ unsigned long long g_bwd_stamps[8192 * 16];
 #define BWD_STAMP(slot, val) \
-  do { if ((threadIdx.x & 63) == 0) g_bwd_stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = (val); } while (0)
+  do { if ((threadIdx.x & 63) == 0) g_bwd_stamps[(size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = (val); } while (0)
 #else
 #define BWD_STAMP(slot, val) do {} while (0)
 #endif
@@ -736,14 +744,23 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
   float* const trash = a.trash + threadIdx.x * C::H;
   const int n_tiles = tile1 - tile0;
   BWD_STAMP(1, wall_clock64());
-  int q_next = QUEUE ? queue_pop(a.tile_q + 1) : 0;
+  int q_raw = 0;                        // (QUEUE) the pending pop: the tile after this one
+  int q_rel = wave;                     // the first tile of a worker is static
   int n_done = 0, n_steps_done = 0;
+#ifdef NJ_BWD_STAMPS
+  unsigned long long t_pro = 0, t_loop = 0, t_pop = 0;
+#endif
   for (int round = 0; QUEUE || round * n_waves < n_tiles; ++round) {
+#ifdef NJ_BWD_STAMPS
+    const unsigned long long tt0 = wall_clock64();
+#endif
     int rel;
     if constexpr (QUEUE) {
-      rel = q_next;
+      rel = round == 0 ? q_rel : n_waves + queue_value(q_raw);
       if (rel >= n_tiles) break;
-      q_next = queue_pop(a.tile_q + 1);   // (for the next round: in flight during this tile)
+#ifdef NJ_BWD_STAMPS
+      t_pop += wall_clock64() - tt0;
+#endif
     } else {
       rel = snake_tile(round, wave, n_waves);
       if (rel >= n_tiles) continue;
@@ -785,6 +802,14 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       rec_load_A<C>(blk, lane, a2, h);
       rec_load_B<C>(blk, lane, a1);
     }
+#ifdef NJ_BWD_STAMPS
+    vm_drain();
+    const unsigned long long tt1 = wall_clock64();
+    t_pro += tt1 - tt0;
+#endif
+    // (behind the prologue's loads: vmcnt retires in order, an atomic in front of them would put its
+    // round trip on the chain order -> item -> record that the first Euler step waits for)
+    if constexpr (QUEUE) q_raw = queue_pop_issue(a.tile_q + 1);
     for (int s = nmax - 1; s >= 0; --s) {
       const float dt = s < it.n ? dt_r : 0.0f, t = t_r;
       const int sp = s > 0 ? s - 1 : 0;
@@ -886,6 +911,9 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       }
       if (!BWD_ABL(4)) wave_lds_sync();
     }
+#ifdef NJ_BWD_STAMPS
+    t_loop += wall_clock64() - tt1;
+#endif
     float* out = valid ? a.lam_start + (size_t)it.r * C::H : trash;
 #pragma unroll
     for (int q = 0; q < M::QH; ++q) {
@@ -895,10 +923,15 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     }
   }
 
+#ifdef NJ_BWD_STAMPS
+  BWD_STAMP(8, t_pro);
+  BWD_STAMP(9, t_loop);
+  BWD_STAMP(10, t_pop);
+#endif
   BWD_STAMP(2, wall_clock64());
   BWD_STAMP(4, (unsigned long long)n_done);
   BWD_STAMP(5, (unsigned long long)n_steps_done);
-  (void)n_done; (void)n_steps_done;
+  (void)n_done; (void)n_steps_done; (void)q_rel;
   if (BWD_ABL(128)) return;
   ode3_flush<C, DROP>(a, lds_raw, G3, G2, GM, GN, G1, slab_row);
   BWD_STAMP(3, wall_clock64());

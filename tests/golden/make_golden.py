@@ -657,8 +657,38 @@ def g13():
     print('{:28s} {:8.1f} KB'.format('g13_f64_truth', os.path.getsize(path) / 1024))
 
 
+def g14():
+    """output_size != input_size (round 5): the reference builds a readout to any output_size
+    (models.py:350-352); the loss compares X with the readout, so such a model is usable with
+    get_loss=False only.  Prediction path of the reference for two shapes: d = 1 -> 5 outputs
+    (residual case 2: H = 10 folded by two) and d = 2 ('power-2') -> 20 outputs (case 1), relu nets."""
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    dt, T = hp['dt'], hp['maturity']
+    nn32 = ((32, 'relu'), (32, 'tanh'))
+    cases = {
+        'g14_out5': (dict(demo_cfg(dropout=0.0), output_size=5), 24, None),
+        'g14_out20': (dict(demo_cfg(d=2, dropout=0.0), output_size=20, ode_nn=nn32, enc_nn=nn32,
+                           readout_nn=nn32), 17, ['power-2']),
+    }
+    for name, (cfg, B, funcs) in cases.items():
+        model = build(cfg)
+        b = ref_collate(paths, obs, nb_obs, dt, range(B), funcs)
+        arrays = {**sd_arrays(model), **batch_arrays(b), 'delta_t': dt, 'T': T}
+        model.eval()
+        with torch.no_grad():
+            hT, loss, path_t, path_h, path_y = model(
+                b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt, T, b['start_X'], b['n_obs_ot'],
+                return_path=True, get_loss=False, until_T=True)
+            hT2, loss2 = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], dt, T, b['start_X'],
+                               b['n_obs_ot'], return_path=False, get_loss=False)
+        assert loss == 0 and loss2 == 0
+        arrays.update({'hT': hT.numpy(), 'path_t': np.asarray(path_t, dtype=np.float64),
+                       'path_h': path_h.numpy(), 'path_y': path_y.numpy(), 'hT_lastobs': hT2.numpy()})
+        save(name, cfg, arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13', 'g14']
     for name in which:
         globals()[name]()

@@ -69,6 +69,10 @@ def test_bench_self_spawns_two_ranks_weak_scaling(tmp_path):
                      share=False)
     assert one['n_gpus'] == 1 and 'rccl_world' not in one
     _check_pair(two, p2, one, p1, 40000, 'weak')
+    # the weak-scaling line also carries the strong-scaling reading of BASELINE's 20 000-path batch
+    assert two['strong_20k_ms'] > 0 and two['strong_20k_paths_per_s'] == pytest.approx(
+        20000 / (two['strong_20k_ms'] * 1e-3), rel=1e-3)
+    assert '10000 paths on rank 0' in two['strong_20k_note']
 
 
 def test_bench_self_spawns_two_ranks_strong_scaling_at_config4_shard_size(tmp_path):
@@ -78,6 +82,7 @@ def test_bench_self_spawns_two_ranks_strong_scaling_at_config4_shard_size(tmp_pa
                      share=False)
     assert two['config']['paths_rank0'] == SHARD
     _check_pair(two, p2, one, p1, g, 'strong')
+    assert 'strong_20k_ms' not in two          # (only beside a WEAK headline)
 
 
 def test_bench_refuses_more_ranks_than_gpus_without_the_self_test_switch():

@@ -128,3 +128,24 @@ def test_shipped_checkpoint_known_answers(tag, name):
 def test_residual_size_check():
     with pytest.raises(ValueError):
         njode_oracle.OracleNJODE(41, 50, 41, None, None, None)
+
+
+@pytest.mark.parametrize('name', ['g14_out5', 'g14_out20'])
+def test_prediction_path_with_output_size_not_input_size(name):
+    """models.py:350-352 builds a readout to ANY output_size; without the loss (get_loss=False)
+    such a model predicts.  The oracle against the reference's own run (make_golden.py:g14)."""
+    g = Golden(name)
+    assert g.cfg['output_size'] != g.cfg['input_size']
+    model = njode_oracle.make_oracle(g.cfg)
+    params = _params(g)
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = _fwd(g, model, params, return_path=True, get_loss=False,
+                                                until_T=True)
+        hT2, loss2 = _fwd(g, model, params, get_loss=False)
+    assert loss == 0 and loss2 == 0
+    assert np.array_equal(path_t, g['path_t'])
+    assert path_y.shape[-1] == g.cfg['output_size']
+    np.testing.assert_allclose(path_y.numpy(), g['path_y'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(path_h.numpy(), g['path_h'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(hT.numpy(), g['hT'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(hT2.numpy(), g['hT_lastobs'], atol=1e-6, rtol=0)

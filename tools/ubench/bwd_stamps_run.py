@@ -42,12 +42,12 @@ def main():
         opt.step()
     torch.cuda.synchronize()
     L = _lib.lib()
-    n_words = 8192 * 8
+    n_words = 8192 * 16
     buf = np.zeros(n_words, dtype=np.uint64)
     L.njode_debug_bwd_stamps.argtypes = [C.c_void_p, C.c_uint64]
     rc = L.njode_debug_bwd_stamps(buf.ctypes.data, n_words)
     assert rc == 0, rc
-    s = buf.reshape(-1, 8)
+    s = buf.reshape(-1, 16)
     grid = int(s[0, 7] >> np.uint64(32))
     T = int((s[0, 7] >> np.uint64(8)) & np.uint64(0xffffff))
     s = s[:grid * 4]
@@ -84,6 +84,9 @@ def main():
             'tiles_per_wave': [int(tiles[m].min()), float(np.round(tiles[m].mean(), 2)), int(tiles[m].max())],
             'steps_per_wave': [int(steps[m].min()), float(np.round(steps[m].mean(), 1)), int(steps[m].max())],
             'us_per_tile_step': round(float(sweep[m].sum() / max(steps[m].sum(), 1)), 3),
+            'tile_prologue_us_per_tile': round(float(s[m, 8].sum() * tick / max(tiles[m].sum(), 1)), 3),
+            'step_loop_us_per_step': round(float(s[m, 9].sum() * tick / max(steps[m].sum(), 1)), 3),
+            'queue_pop_us_per_tile': round(float(s[m, 10].sum() * tick / max(tiles[m].sum(), 1)), 3),
         }
         out[name] = d
         print('  ' + name)
