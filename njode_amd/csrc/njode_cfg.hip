@@ -165,10 +165,12 @@ static void launch_mfma_fwd(const KArgs& a, bool split, hipStream_t st) {
     if constexpr (HAS_SPLIT) {
       if (split) {
         if constexpr (TAIL) {
-          // (small plans: the four-wave form, whose latency per tile IS the kernel time there;
-          // NJODE_TAILS=split keeps it for every plan: A/B)
-          static const bool tails_split = getenv("NJODE_TAILS") && strcmp(getenv("NJODE_TAILS"), "split") == 0;
-          if (n_tiles <= 768 || tails_split)
+          // (the four-wave form for every plan.  NJODE_TAILS=single: one wave per tile on the
+          // scaled fragments for large plans, k_ode_fwd_tails -- measured beside the items' forward
+          // on the autograd route and slower, 1.121 against 1.075 ms per step: 4 096 one-wave blocks
+          // queue behind the forward's, the 1 024 four-wave blocks finish their tiles sooner)
+          static const bool tails_single = getenv("NJODE_TAILS") && strcmp(getenv("NJODE_TAILS"), "single") == 0;
+          if (n_tiles <= 768 || !tails_single)
             k_ode_fwd_split<CC, DROP, true><<<n_tiles < 1024 ? n_tiles : 1024, 256, 0, st>>>(a);
           else
             k_ode_fwd_tails<CC, DROP><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
@@ -220,7 +222,8 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       ProfScope ps("k_pack_all", s2);
       launch_pack_frags<C>(ab, s2, bits);
     }
-    {
+    const bool enc_fused = ODE == ODE_MFMA && HAS_SPLIT && a.enc_fused != 0;
+    if (!enc_fused) {
       ProfScope ps(ODE == ODE_MFMA ? "k_encode_rows_mfma" : "k_encode_rows", s2);
       if constexpr (ODE == ODE_MFMA) launch_mfma_enc<C, DROP>(a, s2);
       else k_encode_rows<C, DROP><<<cdiv(a.n_obs + a.B, 64), 64, 0, s2>>>(a);
@@ -228,6 +231,15 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     if (side) {
       (void)hipEventRecord(side->e1, s2);
       (void)hipStreamWaitEvent(st, side->e1, 0);
+    }
+    if constexpr (ODE == ODE_MFMA && HAS_SPLIT) {
+      if (enc_fused) {
+        // NJODE_ENC_FUSED: what the ODE forward's one-wave role does not evaluate itself (needs the
+        // plan -- the item order and the split point -- so it runs on `st`, behind it)
+        ProfScope ps("k_encode_rows_items", st);
+        const int n_path_tiles = cdiv(a.B, 16);
+        k_encode_rows_items<C, DROP><<<n_path_tiles + a.n_split_fwd * 4, 64, 0, st>>>(a, n_path_tiles);
+      }
     }
     // the tails (hT: every path from its last observation to the end) need the encoder's outputs
     // and nothing else of this call: with helper streams they start TOGETHER with the items' ODE

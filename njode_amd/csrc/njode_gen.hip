@@ -160,7 +160,10 @@ bool build_model(const NjodeDims* d, Model& m, const char** why) {
   a.rnn = (d->flags & NJODE_F_USE_RNN) ? 1 : 0;
   if (a.rnn) {
     // the GRU cell as ONE layer [x; h; 1] -> [r, z, W_in x + b_in, W_hn h + b_hn]  (njode_gen.h, gru_w)
-    if (masked) { *why = "use_rnn with masked data is not built: the reference runs its GRU on the zero-filled X_obs (models.py:460) -- a known gap of this library"; return false; }
+    // (round 5: with masked data the reference runs the cell on the zero-filled X_obs -- no
+    // self-imputation at the jump -- while the start state still goes through the masked encoder,
+    // the loss is masked and last_X <- Y (models.py:411-414, 460-461, 483-484); the lockstep kernels
+    // of this family are written per feature, so the combination needs no code of its own)
     if (4 * H > NJODE_GEN_MAX_WIDTH) { *why = "use_rnn: 4 x hidden_size exceeds the widest layer the kernels take"; return false; }
     GNet1& N = a.gru;
     N.nl = 1;

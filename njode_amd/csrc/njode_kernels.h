@@ -144,6 +144,9 @@ struct KArgs {
   // the other blocks one wave per tile (njode_mfma_split.h); grid sizes
   int n_split_blocks, n_blocks_bwd, n_split_fwd, n_blocks_fwd;
   int q4_pt;       // masked lockstep kernels (njode_mfma_lock4.h): paths per 16-lane tile
+  // segment plan, round 5 (NJODE_ENC_FUSED=1): the one-wave role of k_ode_fwd_mixed evaluates
+  // encoder(X) of an item's START row itself (njode_ode2.h); k_encode_rows_items covers the rest
+  int enc_fused;
   DropCtx dc;
   float keep;
 };

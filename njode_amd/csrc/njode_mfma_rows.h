@@ -482,6 +482,57 @@ __global__ void __launch_bounds__(64) k_encode_rows_mfma(KArgs a) {
   }
 }
 
+// NJODE_ENC_FUSED (njode_ode2.h, ode2_item_start): the encoder evaluations the one-wave role of the
+// ODE forward does NOT do itself -- the start of every item of the four-wave role's tiles (sorted
+// items [0, 16 T), T = the forward's split point, on the device) and, per path, the state after its
+// LAST observation (no item starts there; the row pass and the tails read it; a path without
+// observations: its start value).  Tiles: [0, ceil(B / 16)) the paths, behind them the item tiles.
+template <class C, bool DROP>
+__global__ void __launch_bounds__(64) k_encode_rows_items(KArgs a, int n_path_tiles) {
+  using S = typename EncS<C>::type;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  FwdFrags<S> F;
+  F.load(a.frag_enc, lane);
+  const int T = (int)a.base_s[a.K + 2];
+  const int n_tiles = n_path_tiles + (a.n_obs > 0 ? T : 0);
+  float* const trash = a.trash + lane * C::H;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    bool valid, is_row;
+    int b, row;
+    if (tile < n_path_tiles) {
+      b = tile * 16 + c;
+      valid = b < a.B;
+      b = valid ? b : 0;
+      row = a.last_row[b];
+      is_row = row >= 0;
+    } else {
+      const int j = (tile - n_path_tiles) * 16 + c;
+      valid = j < a.n_obs;
+      const int r = a.order[valid ? j : 0];
+      b = a.obs_idx[r];
+      row = a.item_prev[r];
+      is_row = row >= 0;
+    }
+    const int rr = is_row ? row : 0;
+    const float* xp = is_row ? a.X + (size_t)rr * C::D : a.start_X + (size_t)b * C::D;
+    float b0[S::Q0], a1[S::Q1], a2[S::Q1];
+    enc_input<C, S>(xp, b0, g);
+    uint32_t k1, k2;
+    row_keep_bits<DROP>(a, a.gid0 + b, is_row ? (uint32_t)a.k_jump[a.t_of_row[rr]] : TKEY_START, NET_ENC, g,
+                        S::Q1, k1, k2);
+    f32x4 out[S::MTO];
+    mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+    float* dstrow = valid ? (is_row ? a.h0row + (size_t)rr * C::H : a.h0start + (size_t)b * C::H) : trash;
+#pragma unroll
+    for (int q = 0; q < S::QO; ++q) {
+      const int u = 4 * q + g;
+      const float v = out[q / 4][q % 4] + enc_residual<C>(xp, u < C::H ? u : 0);
+      float* dst = u < C::H ? dstrow + u : trash;
+      *dst = v;
+    }
+  }
+}
+
 // readout input [tanh(h) (H), 1] from a row of H floats
 template <class C, class S>
 NJ_DEV void dec_input(const float* hp, float (&b0)[S::Q0], int g) {

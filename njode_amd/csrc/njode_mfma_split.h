@@ -813,7 +813,8 @@ __global__ void __launch_bounds__(64) k_ode_fwd_tails(KArgs a) {
 // single-wave kernels' rate.
 template <class C, bool DROP>
 __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS];
+  // (behind the four-wave role's exchange images: the encoder's forward fragments, NJODE_ENC_FUSED)
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS + EncFwdLds<C>::FLOATS];
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_fwd;
   const int T = (int)a.base_s[a.K + 2];
   const bool save = a.save_traj != 0;   // wave-uniform: a training forward stores checkpoints
@@ -828,6 +829,14 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
     const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
     // one-wave role on the scaled fragments (njode_ode2.h): same masks, same values to rounding
     const int nw = ((int)gridDim.x - ns) * 4;
+    if (a.enc_fused) {   // (uniform) the wave evaluates the encoder at the head of every item
+      lfp enc_img = (lfp)lds_raw + OdeFwdSplitLds<C>::FLOATS;
+      EncFwdLds<C>::stage(enc_img, a.frag_enc, threadIdx.x, 256);
+      __syncthreads();
+      if (save) ode2_fwd_single<C, DROP, false, true, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles, enc_img);
+      else ode2_fwd_single<C, DROP, false, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles, enc_img);
+      return;
+    }
     if (save) ode2_fwd_single<C, DROP, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
     else ode2_fwd_single<C, DROP, false, false>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
   }

@@ -17,6 +17,7 @@
 //    tools/ubench/njode_ode2_proto.h, which only tools/ubench/ode_ubench.hip compiles.)
 #pragma once
 #include "njode_mfma.h"
+#include "njode_mfma_rows.h"
 
 namespace njode {
 
@@ -388,15 +389,65 @@ NJ_DEV void out_layer2(const float (&A3)[MF<C>::MTH][MF<C>::Q1], const float (&a
   }
 }
 
+// start state of an item from the encoder (ENC of ode2_fwd_single): h = encoder_map(X of the
+// start row) + identity path, D-layout; stored as h0row[start row] (start values: h0start[path])
+// for the kernels behind the forward
+// forward fragments of the encoder only (S::NFWD vectors), one copy per block
+template <class C> struct EncFwdLds {
+  using S = typename EncS<C>::type;
+  static constexpr int FLOATS = S::NFWD * 64;
+  static NJ_DEV void stage(lfp img, const float* frag_enc, int tid, int nthreads) {
+    for (int i = tid; i < FLOATS; i += nthreads) img[i] = frag_enc[i];
+  }
+};
+template <class C, bool DROP>
+NJ_DEV void ode2_item_start(const KArgs& a, const Item<C>& it, bool valid, lfp enc_img, int lane,
+                            float (&h)[MF<C>::QH]) {
+  using S = typename EncS<C>::type;
+  static_assert(S::QO == MF<C>::QH && S::MTO == MF<C>::MTH, "encoder output = ODE state");
+  const int g = lane >> 4;
+  const bool is_row = it.prev >= 0;
+  const int pv = is_row ? it.prev : 0;
+  const float* xp = is_row ? a.X + (size_t)pv * C::D : a.start_X + (size_t)it.b * C::D;
+  float b0[S::Q0], a1[S::Q1], a2[S::Q1];
+  enc_input<C, S>(xp, b0, g);
+  uint32_t k1, k2;
+  row_keep_bits<DROP>(a, a.gid0 + it.b, is_row ? (uint32_t)a.k_jump[a.t_of_row[pv]] : TKEY_START, NET_ENC, g,
+                      S::Q1, k1, k2);
+  LdsFrags<S> F;
+  F.init(enc_img, lane);
+  f32x4 out[S::MTO];
+  mnet_fwd<S, C::ACT, DROP>(F, b0, a1, a2, out, k1, k2, a.dc.inv_keep, g);
+  float* const trash = a.trash + lane * C::H;
+  float* dstrow = valid ? (is_row ? a.h0row + (size_t)pv * C::H : a.h0start + (size_t)it.b * C::H) : trash;
+#pragma unroll
+  for (int q = 0; q < S::QO; ++q) {
+    const int u = 4 * q + g;
+    const float v = out[q / 4][q % 4] + enc_residual<C>(xp, u < C::H ? u : 0);
+    h[q] = u < C::H ? v : 0.0f;
+    float* dst = u < C::H ? dstrow + u : trash;
+    *dst = v;
+  }
+}
+
 // B (v2): Euler evolve of every item; worker `wave` of `n_waves` walks the tiles
 // [tile0, tile1) in snake order.  Same contract as ode_fwd_single (njode_mfma.h) with the
 // scaled fragment table a.frag2.
 // SAVE (compile time: checkpoints + activations are stored without a branch, so the compiler
 // can COUNT them -- with a runtime `if` around the stores every `s_waitcnt vmcnt` that waits for
 // the next step's prefetched scalars conservatively also drained the stores: +13 % on the kernel)
-template <class C, bool DROP, bool TAIL, bool SAVE>
-NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int tile0, int tile1) {
+// ENC (round 5, NJODE_ENC_FUSED=1; VERDICT r4 item 4's structural option): an item starts at
+// encoder(X of its start row) -- one encoder evaluation per item -- so the wave evaluates it itself
+// at the head of the item (fragments from the block's LDS image `enc_img`, the S::NFWD forward
+// vectors of the encoder; same matrix instructions, same dropout words as k_encode_rows_mfma: the
+// same numbers) and stores h0row[start row] for the row pass, instead of reading what a separate
+// launch over all rows wrote.  k_encode_rows_items then only covers the start rows of the four-wave
+// role's tiles and every path's LAST row (no item starts there).
+template <class C, bool DROP, bool TAIL, bool SAVE, bool ENC = false>
+NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int tile0, int tile1,
+                            lfp enc_img = nullptr) {
   static_assert(!(TAIL && SAVE), "tail items are never checkpointed");
+  static_assert(!(TAIL && ENC), "tails read the stored state after their last observation");
   using M = MF<C>;
   const int g = lane >> 4, c = lane & 15;
   Ode2FwdFrags<C> F;
@@ -415,12 +466,16 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
     const bool valid = j < n_items;
     Item<C> it;
     it.template load<TAIL>(a, j, valid);
-    const float* h0 = it.h0(a);
     float h[M::QH];
+    if constexpr (ENC) {
+      ode2_item_start<C, DROP>(a, it, valid, enc_img, lane, h);
+    } else {
+      const float* h0 = it.h0(a);
 #pragma unroll
-    for (int q = 0; q < M::QH; ++q) {
-      const int u = 4 * q + g;
-      h[q] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
+      for (int q = 0; q < M::QH; ++q) {
+        const int u = 4 * q + g;
+        h[q] = u < C::H ? h0[u < C::H ? u : 0] : 0.0f;
+      }
     }
     // (uniform: the step loop is a scalar loop, base16_s[s] a scalar load; the per-lane
     // schedule values of the next step are loaded one step ahead and carried RAW across the
@@ -652,20 +707,20 @@ NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<
     }
 }
 
-// ---- tile queue (round 5) --------------------------------------------------------------------
+// ---- tile queue (round 5; NJODE_BWD_QUEUE=1, not the default) ----------------------------------
 // The backward's gradient accumulators persist across the tiles of a worker, so its blocks cannot
-// be handed out by the dispatcher as the forward's are: rounds 2-4 gave every worker its tiles
+// be handed out by the dispatcher as the forward's are: rounds 2-4 give every worker its tiles
 // statically (snake order over 1 024 blocks, two per CU resident: the second half of the blocks
-// starts as first-half blocks retire, each with a prologue and a flush of its own, and whatever a
-// SIMD loses to its neighbours shows as idle time at the end of the launch,
-// profiles/r05_bwd_fixed_costs.txt).  Now the launch is exactly the resident blocks and every
-// worker pops the next tile -- longest first, the tiles are sorted -- from a counter in the
-// workspace: KArgs::tile_q[0] for the tiles [0, T) of the four-wave role, [1] for the bulk
-// [T, n_tiles), [2] counts finished blocks (the last one clears all three for the next launch;
-// the saving forward clears them once, too).  The pop for the NEXT tile is issued when a tile
-// starts, so its round trip to L2 hides behind the sweep.  Which tiles meet in one accumulator now
-// depends on timing: gradients agree between runs to fp32 summation order, not bitwise;
-// NJODE_BWD_QUEUE=0 restores the static rounds.
+// starts as first-half blocks retire, and a third of the wave slots' time is idle at the end of
+// the launch).  With the queue the launch is exactly the resident blocks and every worker pops
+// the next tile -- longest first, the tiles are sorted -- from a counter in the workspace:
+// KArgs::tile_q[0] for the tiles [0, T) of the four-wave role, [1] for the bulk [T, n_tiles), [2]
+// counts finished blocks (the last one clears all three for the next launch; the saving forward
+// clears them once, too).  Measured (profiles/r05_bwd_fixed_costs.txt): the idle time goes (35 %
+// -> 6 % of wave time) and the launch does not get shorter, because the Euler-step loop is bound by
+// the SIMD's pipe: kept as a switch, the static rounds stay the default -- they also keep the
+// gradient bitwise reproducible (with the queue, which tiles meet in one accumulator depends on
+// timing: equal to fp32 summation order only).
 // (the pop is issued WITHOUT a wait -- lane 0's register holds the counter's old value once the
 // atomic has returned; queue_value() reads it when the next tile starts, a whole tile later.
 // profiles/r05_bwd_fixed_costs.txt: waited for at once, the round trip of 1 920 waves popping one

@@ -456,9 +456,6 @@ class NJODE(torch.nn.Module):
     def _get_dims(self):
         if self._dims is not None:
             return self._dims
-        if self.use_rnn and self.masked:
-            raise NotImplementedError('use_rnn with masked data is not defined by the reference '
-                                      '(models.py:353 TODO)')
         if self.solver != 'euler':
             raise ValueError("Unknown solver '{}'.".format(self.solver))
         flags = ((_lib.F_MASKED if self.masked else 0)

@@ -687,8 +687,25 @@ def g14():
         save(name, cfg, arrays)
 
 
+def g15():
+    """use_rnn WITH masked data (round 5).  `models.py:353` carries a TODO, but the model runs: the
+    GRU cell sees the zero-filled X_obs (no self-imputation at the jump, :460-461), the start state
+    goes through the masked encoder (:411-414), the loss is masked, last_X <- Y (:483-484).  The
+    reference's own prediction path, loss and gradients on a small PhysioNet-shaped batch."""
+    cfg = dict(input_size=5, hidden_size=10, output_size=5, ode_nn=NN, readout_nn=NN, enc_nn=NN,
+               use_rnn=True, bias=True, dropout_rate=0.0, options={'masked': True})
+    b = synthetic_physionet.make_batch(batch_size=21, dim=5, n_grid=70, n_obs_range=(4, 11),
+                                       p_feature=0.4, seed=9)
+    model = build(cfg)
+    arrays = {**sd_arrays(model), **batch_arrays(b, with_M=True), 'delta_t': b['delta_t'], 'T': b['T']}
+    out = eval_outputs(model, b, b['delta_t'], b['T'], M=b['M'])
+    arrays.update(out)
+    arrays.update(grad_outputs(model, b, b['delta_t'], b['T'], M=b['M']))
+    save('g15_rnn_masked', cfg, arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13', 'g14']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13', 'g14', 'g15']
     for name in which:
         globals()[name]()

@@ -372,3 +372,26 @@ def test_output_size_other_than_input_size_predicts_and_refuses_the_loss(name):
     np.testing.assert_allclose(hT2.cpu().numpy(), g['hT_lastobs'], atol=ATOL, rtol=RTOL)
     with pytest.raises(Exception, match='input_size != output_size'):
         hip_forward(m, g.batch(), g.delta_t, g.T)          # get_loss=True
+
+
+def test_use_rnn_with_masked_data_matches_reference():
+    """Round 5: the GRU jump with masked data (reference: models.py:353 TODO, :460-461 -- it runs):
+    prediction path, loss and every gradient against the reference's own run (make_golden.py:g15)."""
+    from golden_util import Golden
+    from hip_util import hip_forward, hip_model
+    g = Golden('g15_rnn_masked')
+    m = hip_model(g.cfg, g.state_dict()).eval()
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = hip_forward(m, g.batch(), g.delta_t, g.T, return_path=True,
+                                                       get_loss=True, until_T=True)
+    assert np.array_equal(path_t, g['path_t'])
+    np.testing.assert_allclose(path_y.cpu().numpy(), g['path_y'], atol=2e-5, rtol=RTOL)
+    np.testing.assert_allclose(hT.cpu().numpy(), g['hT'], atol=2e-5, rtol=RTOL)
+    assert float(loss) == pytest.approx(float(g['loss']), rel=LOSS_RTOL)
+    m.train()
+    _, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g['train_loss']), rel=LOSS_RTOL)
+    got = grads_by_name(m)
+    for k, ref in g.group('grad').items():
+        assert rel_l2(got[k], ref) < GRAD_REL_L2, (k, rel_l2(got[k], ref))

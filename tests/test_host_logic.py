@@ -253,9 +253,17 @@ def test_library_loads_and_exports_declared_symbols():
     assert L.njode_param_count(ctypes.byref(d5)) == \
         (12 * 50 + 50) + (50 * 50 + 50) + (50 * 7 + 7) + (3 * 50 + 50) + (50 * 50 + 50) + (50 * 7 + 7) + \
         (7 * 50 + 50) + (50 * 50 + 50) + (50 * 3 + 3) + (21 * 3 + 21 * 7 + 21 + 21)
-    # ... but not with masked data, which the reference leaves undefined (models.py:353)
+    # (round 5: ... and with masked data too -- models.py:353 has a TODO, but the model runs; the
+    # masked encoder takes [x, mask]: 2 x 3 inputs)
     d2 = _lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_USE_RNN | _lib.F_MASKED)
+    assert L.njode_supported(ctypes.byref(d2)) == 1
+    assert L.njode_param_count(ctypes.byref(d2)) == L.njode_param_count(ctypes.byref(d5)) + 3 * 50
+    # a GRU cell wider than the widest layer of the generic kernels (4 x hidden_size > 1 024)
+    d2 = _lib.NjodeDims(3, 300, 3, 2, 50, 0, _lib.F_USE_RNN)
     assert L.njode_supported(ctypes.byref(d2)) == 0
+    # round 5: output_size != input_size runs (prediction calls) -- unless masked
+    assert L.njode_supported(ctypes.byref(_lib.NjodeDims(3, 6, 12, 2, 50, 0, 0))) == 1
+    assert L.njode_supported(ctypes.byref(_lib.NjodeDims(3, 6, 12, 2, 50, 0, _lib.F_MASKED))) == 0
     assert L.njode_supported(ctypes.byref(_lib.NjodeDims(3, 7, 3, 2, 50, 0, _lib.F_RESIDUAL))) == 0
     need = ctypes.c_size_t(0)
     assert L.njode_workspace_bytes(ctypes.byref(d), 100, 1000, 100, 100,

@@ -149,3 +149,25 @@ def test_prediction_path_with_output_size_not_input_size(name):
     np.testing.assert_allclose(path_h.numpy(), g['path_h'], atol=1e-6, rtol=0)
     np.testing.assert_allclose(hT.numpy(), g['hT'], atol=1e-6, rtol=0)
     np.testing.assert_allclose(hT2.numpy(), g['hT_lastobs'], atol=1e-6, rtol=0)
+
+
+def test_use_rnn_with_masked_data_matches_reference():
+    """models.py:353 has a TODO, yet the combination runs (GRU on the zero-filled X_obs, masked
+    encoder for the start state, masked loss, last_X <- Y): the oracle against the reference's run."""
+    g = Golden('g15_rnn_masked')
+    model = njode_oracle.make_oracle(g.cfg)
+    params = _params(g)
+    with torch.no_grad():
+        hT, loss, path_t, path_h, path_y = _fwd(g, model, params, return_path=True, get_loss=True,
+                                                until_T=True)
+    assert np.array_equal(path_t, g['path_t'])
+    np.testing.assert_allclose(path_y.numpy(), g['path_y'], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(hT.numpy(), g['hT'], atol=1e-6, rtol=0)
+    assert float(loss) == pytest.approx(float(g['loss']), rel=1e-6)
+    model.training = True
+    params = _params(g, requires_grad=True)
+    _, loss = _fwd(g, model, params)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g['train_loss']), rel=1e-6)
+    for k, ref in g.group('grad').items():
+        np.testing.assert_allclose(params[k].grad.numpy(), ref, atol=1e-6, rtol=1e-4)
