@@ -106,8 +106,10 @@ typedef struct NjodeDims {
                                    For callers whose saving forward is always followed by its backward
                                    (an autograd bridge): the readouts are evaluated once, not twice.
                                    Same value to the forward and its backward.                        */
-#define NJODE_C_GEN_LOCKSTEP 0x200 /* shape-generic kernels: keep an unmasked loss call on the lockstep
-                                   plan (A/B runs, tests).  A CALL flag -- the same value must be
+#define NJODE_C_GEN_LOCKSTEP 0x200 /* keep an unmasked loss call on the LOCKSTEP plan (both kernel
+                                   families since round 5; round 4: the shape-generic one): A/B runs,
+                                   tests, and the pass that differentiates through hT
+                                   (NjodeBatch.grad_hT).  A CALL flag -- the same value must be
                                    given to njode_plan_f32, the forward and its backward, which lay
                                    the plan and the workspace out by it -- not an environment
                                    variable the library would re-read in each of the three       */
@@ -149,6 +151,14 @@ typedef struct NjodeBatch {
   int64_t path_id_offset;  /* global id of path 0 (dropout streams are keyed by it)   */
   const void* plan;        /* NJODE_C_PLAN_READY: the buffer njode_plan_f32 filled for */
                            /* this batch, schedule and call_flags; else ignored (NULL) */
+  const float* grad_hT;    /* njode_backward_f32 only, or NULL: [B, H] upstream gradient of  */
+                           /* hT (the reference returns hT inside its autograd graph,        */
+                           /* models.py:414-518).  Added to the adjoint of the final state   */
+                           /* by the LOCKSTEP plan's sweep -- i.e. the call must run that    */
+                           /* plan (masked / use_rnn models, schedules with a tail, or       */
+                           /* NJODE_C_GEN_LOCKSTEP); a segment-plan backward returns         */
+                           /* NJODE_E_UNSUPPORTED for a non-NULL value.  grad_params then    */
+                           /* is grad_loss * (d loss / d params + d <grad_hT, hT> / d params) */
 } NjodeBatch;
 
 /* ---- queries ----------------------------------------------------------------- */

@@ -64,7 +64,7 @@ class NjodeBatch(C.Structure):
                 ('start_X', C.c_void_p), ('X', C.c_void_p), ('M', C.c_void_p),
                 ('obs_idx', C.c_void_p), ('n_obs_ot', C.c_void_p),
                 ('loss_batch_size', C.c_float), ('path_id_offset', C.c_int64),
-                ('plan', C.c_void_p)]
+                ('plan', C.c_void_p), ('grad_hT', C.c_void_p)]
 
 
 class NjodeSde(C.Structure):

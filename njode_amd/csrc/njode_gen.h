@@ -132,6 +132,7 @@ struct GArgs {
   float* path_h;
   float* path_y;
   float* loss_terms;     // [B]
+  const float* g_hT;     // [B][H] upstream gradient of hT for the lockstep backward (NjodeBatch.grad_hT), or null
   int save, want_path, want_loss, drop;
   DropCtx dc;
   float keep, weight;
@@ -855,6 +856,12 @@ __global__ void __launch_bounds__(1024) k_gen_bwd(GArgs a) {
   // adjoints: lam_h = S.h [H], lam_x = S.tx [D] (w.r.t. last_X, masked models)
   lfp lam_h = S.h, lam_x = S.tx, dy = S.y, dybj = S.ybj, lam_hn = S.hn;
   const bool drop = a.drop != 0;
+  if (a.g_hT) {   // the adjoint of the final state starts from the upstream gradient of hT
+    for (int e = tid; e < a.H * 16; e += nth) {
+      const int j = e >> 4, c = e & 15;
+      lam_h[e] = c < nv ? a.g_hT[(size_t)(b0 + c) * a.H + j] : 0.0f;
+    }
+  }
   __syncthreads();
   for (int k = a.K; k >= 0; --k) {
     if (k < a.K) {

@@ -478,6 +478,7 @@ int prepare(Call& c, const NjodeDims* dims, const float* params, const NjodeBatc
   a.B = B; a.T = c.L.T; a.PT = c.L.PT; a.n_obs = n_obs; a.K = K; a.n_times = nt;
   a.start_X = b->start_X; a.X = b->X; a.M = b->M; a.n_obs_ot = b->n_obs_ot;
   a.inv_batch = 1.0f / b->loss_batch_size;
+  a.g_hT = nullptr;      // (gen_backward sets it)
   a.gid0 = (unsigned long long)b->path_id_offset;
   const float* sb = (const float*)(pw + c.L.sched);
   a.step_dt = sb;
@@ -690,6 +691,10 @@ int gen_backward(const NjodeDims* dims, const float* params, const NjodeBatch* b
   if (!(call_flags & NJODE_C_SAVE_BWD) || !(call_flags & NJODE_C_GET_LOSS))
     return fail(NJODE_E_BADARG, "backward needs a forward with NJODE_C_SAVE_BWD | NJODE_C_GET_LOSS");
   // (schedule copy, plan, fragment tables and records are where the forward left them)
+  if (b->grad_hT && c.L.seg)
+    return fail(NJODE_E_UNSUPPORTED, "NjodeBatch.grad_hT: the segment plan does not differentiate through hT; "
+                                     "run the step with NJODE_C_GEN_LOCKSTEP");
+  c.a.g_hT = b->grad_hT;
   if (c.L.seg) {
     const int nth = c.m.nw * 64, lds = c.m.lds_bytes;
     if ((rc = set_lds((const void*)k_gseg_ode_bwd, lds)) || (rc = set_lds((const void*)k_gseg_enc_bwd, lds)))

@@ -128,6 +128,8 @@ struct KArgs {
   int n_waves;      // persistent gradient kernels (VALU): waves == slab rows
   int n_waves_ode;  // same for the ODE backward kernel
   int n_waves_rows; // same for the row backward kernels on the matrix cores
+  // lockstep backward: upstream gradient of hT [B][H] (NjodeBatch.grad_hT), or null
+  const float* g_hT;
   // outputs
   float* hT;
   float* path_h;

@@ -72,8 +72,9 @@ __global__ void __launch_bounds__(64, 1) k_paths_bwd_adj(KArgs a) {
   float* const trash = a.trash + threadIdx.x * (C::H > C::D ? C::H : C::D);
 
   float lam_h[C::H], lam_x[C::D];
+  // (the adjoint of the final state: the upstream gradient of hT, if the caller has one)
 #pragma unroll
-  for (int q = 0; q < C::H; ++q) lam_h[q] = 0.0f;
+  for (int q = 0; q < C::H; ++q) lam_h[q] = (a.g_hT && valid) ? a.g_hT[(size_t)b * C::H + q] : 0.0f;
 #pragma unroll
   for (int q = 0; q < C::D; ++q) lam_x[q] = 0.0f;
   int src = a.last_row[b];

@@ -830,6 +830,11 @@ __global__ void __launch_bounds__(256) k_paths_bwd_adj_q4(KArgs a) {
   for (int r = 0; r < 4; ++r) uo[r] = 16 * w + 4 * r + g;
 
   float lam[4] = {0.f, 0.f, 0.f, 0.f};   // adjoint of h, own units
+  if (a.g_hT) {                          // (uniform) ... starting from the upstream gradient of hT
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      lam[r] = (valid && uo[r] < H) ? a.g_hT[(size_t)b * H + (uo[r] < H ? uo[r] : 0)] : 0.0f;
+  }
   float d1acc[4] = {0.f, 0.f, 0.f, 0.f};   // sum of delta1 over the steps of the segment, own units
   // The row this path reverses next (`src`), what the sweep needs of it (its time index, its
   // predecessor row, h before the jump, X, M, y, y_bj: own units), loaded when `src` is assigned --

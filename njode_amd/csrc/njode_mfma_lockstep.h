@@ -466,8 +466,12 @@ __global__ void __launch_bounds__(64, 1) k_paths_bwd_adj_mfma(KArgs a) {
   const cfp sdt = as_cfp(a.step_dt), stt = as_cfp(a.step_t);
 
   float lam_h[M::QH], lx[M::Q0], tx[D];
+  // (the adjoint of the final state: the upstream gradient of hT, if the caller has one)
 #pragma unroll
-  for (int q = 0; q < M::QH; ++q) lam_h[q] = 0.0f;
+  for (int q = 0; q < M::QH; ++q) {
+    const int u = 4 * q + g;
+    lam_h[q] = (a.g_hT && valid && u < H) ? a.g_hT[(size_t)b * H + (u < H ? u : 0)] : 0.0f;
+  }
 #pragma unroll
   for (int q = 0; q < M::Q0; ++q) lx[q] = 0.0f;
   int src = a.last_row[b];

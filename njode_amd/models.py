@@ -190,7 +190,7 @@ class _Call:
     Dropping the last reference (e.g. an autograd graph that is never back-propagated)
     returns the workspace to the model's pool."""
     __slots__ = ('dims', 'batch', 'sched', 'flags', 'weight', 'p_drop', 'seed', 'ws',
-                 'keep', 'ws_slot')
+                 'keep', 'ws_slot', 'sched_obj', 'time_ptr')
 
     def __del__(self):
         slot = getattr(self, 'ws_slot', None)
@@ -213,36 +213,43 @@ class _Plan:
             pool.append(buf)
 
 
-_HT_GRAD_MSG = ('njode_amd: a gradient with respect to hT was requested.  The HIP backward '
-                '(njode_backward_f32) differentiates the LOSS only -- the reference returns hT inside '
-                'its autograd graph (models.py:414-518), this build does not propagate through it and '
-                'refuses instead of returning a gradient that silently ignores the hT term.  Use the '
-                'loss alone, or hT.detach().')
+def _hT_and_loss_grads(model, call, grad_loss, grad_hT):
+    """Flat parameter gradient of  grad_loss * loss + <grad_hT, hT>  for a saved forward ``call``.
+    The loss term is the call's own backward (whatever plan it ran).  The hT term -- the reference
+    returns hT inside its autograd graph, models.py:414-518 -- is a second pass: the same step once
+    more on the LOCKSTEP plan (whose adjoint sweep can start from an upstream gradient of the final
+    state: NjodeBatch.grad_hT) with the loss switched off (loss_batch_size = inf), same dropout
+    seed, i.e. the same masks.  It costs a lockstep forward + backward and is only paid by a
+    backward pass that really reaches hT (``train.py`` never does)."""
+    grad_flat = torch.empty_like(model._flat)
+    dev = model._flat.device
+    if grad_loss is None:
+        grad_loss = torch.zeros(1, device=dev)
+    g = grad_loss.to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+    model._run_backward(call, g, grad_flat)
+    if grad_hT is not None:
+        grad_flat += model._grad_through_hT(call, grad_hT)
+    model._release_ws(call)
+    return grad_flat
 
 
 class _NJODEFunction(torch.autograd.Function):
-    """(loss, hT) = F(params); backward = exact discrete adjoint of the LOSS (njode_backward_f32).
-    hT is returned through the node so that a loss which touches it fails loudly (_HT_GRAD_MSG)
-    instead of being differentiated as if hT were a constant."""
+    """(loss, hT) = F(params); backward = exact discrete adjoint (njode_backward_f32); a gradient
+    that reaches hT adds the pass of ``_hT_and_loss_grads``."""
 
     @staticmethod
     def forward(ctx, model, call, loss, hT, *params):
         ctx.model = model
         ctx.call = call
         ctx.set_materialize_grads(False)
-        return loss.clone(), hT.view_as(hT)
+        # (views, not copies: `loss` and `hT` are this call's own fresh tensors; a clone was one more
+        # 5 us launch on the chain between the forward's last kernel and the backward's first)
+        return loss.view_as(loss), hT.view_as(hT)
 
     @staticmethod
     def backward(ctx, grad_loss, grad_hT):
-        if grad_hT is not None:
-            raise NotImplementedError(_HT_GRAD_MSG)
         model, call = ctx.model, ctx.call
-        grad_flat = torch.empty_like(model._flat)
-        if grad_loss is None:
-            grad_loss = torch.zeros(1, device=model._flat.device)
-        g = grad_loss.to(device=model._flat.device, dtype=torch.float32).reshape(1).contiguous()
-        model._run_backward(call, g, grad_flat)
-        model._release_ws(call)
+        grad_flat = _hT_and_loss_grads(model, call, grad_loss, grad_hT)
         grads = [grad_flat[off:off + n].view(shape) for (off, n, shape) in model._param_slices]
         return (None, None, None, None) + tuple(grads)
 
@@ -600,6 +607,7 @@ class NJODE(torch.nn.Module):
         call.ws_slot = self._acquire_ws(need.value, dev)
         call.ws = call.ws_slot[0]
         call.keep = keep + [pinned]
+        call.sched_obj, call.time_ptr = sched, time_ptr      # (what _grad_through_hT re-packs)
         return call, sched, slot_i, B
 
     def _run_forward(self, call, hT, loss, path_h, path_y, slot_i, stream=None):
@@ -640,6 +648,54 @@ class NJODE(torch.nn.Module):
             ctypes.byref(call.sched), call.flags, call.weight, call.p_drop, call.seed,
             grad_loss.data_ptr(), grad_flat.data_ptr(), call.ws.data_ptr(), call.ws.numel(),
             stream.cuda_stream))
+
+    def _grad_through_hT(self, call, grad_hT, stream=None):
+        """d <grad_hT, hT> / d params (flat) for the saved forward ``call``: see
+        ``_hT_and_loss_grads``."""
+        L = _lib.lib()
+        dev = self._flat.device
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        if not (call.flags & _lib.C_GET_LOSS):
+            raise NotImplementedError('gradient through hT of a get_loss=False call')
+        sched, time_ptr = call.sched_obj, call.time_ptr
+        slot_i, pinned = self._ring.acquire(sched.packed_nbytes())
+        K, nt = sched.pack_into(pinned.numpy(), time_ptr)
+        base = pinned.data_ptr()
+        cs = _lib.NjodeSchedule(K, nt, base, base + 4 * K, base + 8 * K, base + 8 * K + 4 * nt,
+                                base + 8 * K + 8 * nt)
+        b0 = call.batch
+        B, H = int(b0.batch_size), self.hidden_size
+        gh = grad_hT.to(device=dev, dtype=torch.float32).reshape(B, H).contiguous()
+        # loss_batch_size = inf: every loss term (and its gradient) is scaled by 1 / inf = 0
+        cb = _lib.NjodeBatch(b0.batch_size, b0.n_obs, b0.start_X, b0.X, b0.M, b0.obs_idx, b0.n_obs_ot,
+                             float('inf'), b0.path_id_offset, None, None)
+        flags = ((call.flags & (_lib.C_TRAIN | _lib.C_SCHED_KNOWN | _lib.C_SCHED_TAIL))
+                 | _lib.C_GET_LOSS | _lib.C_SAVE_BWD | _lib.C_GEN_LOCKSTEP)
+        need = ctypes.c_size_t(0)
+        _lib.check(L.njode_workspace_bytes(ctypes.byref(call.dims), B, int(b0.n_obs), nt, K, flags,
+                                           ctypes.byref(need)))
+        slot = self._acquire_ws(need.value, dev)
+        try:
+            ws = slot[0]
+            hT2 = torch.empty(B, H, dtype=torch.float32, device=dev)
+            loss2 = torch.zeros(1, dtype=torch.float32, device=dev)
+            rc = L.njode_forward_f32(
+                ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(cb), ctypes.byref(cs), flags,
+                call.weight, call.p_drop, call.seed, hT2.data_ptr(), loss2.data_ptr(), None, None,
+                ws.data_ptr(), ws.numel(), stream.cuda_stream)
+            self._ring.release_after(slot_i, stream)
+            _lib.check(rc)
+            out = torch.empty_like(self._flat)
+            one = torch.ones(1, dtype=torch.float32, device=dev)
+            cb.grad_hT = gh.data_ptr()
+            _lib.check(L.njode_backward_f32(
+                ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(cb), ctypes.byref(cs), flags,
+                call.weight, call.p_drop, call.seed, one.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                ws.numel(), stream.cuda_stream))
+        finally:
+            slot[1] = False
+        return out
 
     # -- plan ahead (njode_plan_f32) --------------------------------------------------------
     def prefetch_plan(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,

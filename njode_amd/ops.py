@@ -99,22 +99,14 @@ def _setup_context(ctx, inputs, output):
 
 
 def _backward(ctx, grad_hT, grad_loss, grad_id):
-    if grad_hT is not None:
-        # the library differentiates the loss only; a loss that touches hT must not get a
-        # gradient that silently drops that term (reference: hT is inside the graph)
-        from .models import _HT_GRAD_MSG
-        raise NotImplementedError(_HT_GRAD_MSG)
+    from .models import _hT_and_loss_grads
     model = _MODELS[ctx.model_id]
     call = _CALLS.pop(ctx.call_id, None)
     if call is None:
         raise RuntimeError('njode_amd::forward was not run with save_bwd=True, or its backward '
                            'already ran (a second backward is not supported)')
-    grad_flat = torch.empty_like(model._flat)
-    if grad_loss is None:
-        grad_loss = torch.zeros(1, device=model._flat.device)
-    g = grad_loss.to(device=model._flat.device, dtype=torch.float32).reshape(1).contiguous()
-    model._run_backward(call, g, grad_flat)
-    model._release_ws(call)
+    # (round 4 received grad_hT here and dropped it; now the hT term is differentiated too)
+    grad_flat = _hT_and_loss_grads(model, call, grad_loss, grad_hT)
     grads = [grad_flat[off:off + n].view(shape) for (off, n, shape) in model._param_slices]
     return (grads,) + (None,) * 13
 

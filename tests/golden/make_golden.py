@@ -704,8 +704,49 @@ def g15():
     save('g15_rnn_masked', cfg, arrays)
 
 
+def g16():
+    """Gradient THROUGH hT (round 5): the reference returns hT inside its autograd graph
+    (models.py:414-518).  For a fixed weight tensor W the reference's gradients of
+    loss + <W, hT>  and of  <W, hT>  alone (train mode, dropout 0), on the demo shape (segment plan),
+    a PhysioNet-shaped masked model, the GRU jump and a width-100 model (shape-generic kernels)."""
+    paths, obs, nb_obs, hp, _ = ref_dataset('BlackScholes', 200)
+    dt, T = hp['dt'], hp['maturity']
+    nn100 = ((100, 'tanh'), (100, 'tanh'))
+    cases = {
+        'g16_hT_demo': (demo_cfg(dropout=0.0), ref_collate(paths, obs, nb_obs, dt, range(24)), dt, T, None),
+        'g16_hT_rnn': (dict(demo_cfg(dropout=0.0), use_rnn=True), ref_collate(paths, obs, nb_obs, dt, range(30, 49)), dt, T, None),
+        'g16_hT_w100': (dict(demo_cfg(dropout=0.0), ode_nn=nn100, enc_nn=nn100, readout_nn=nn100),
+                        ref_collate(paths, obs, nb_obs, dt, range(60, 71)), dt, T, None),
+    }
+    bm = synthetic_physionet.make_batch(batch_size=9, n_grid=120, n_obs_range=(4, 14), seed=4)
+    cases['g16_hT_masked'] = (dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN,
+                                   enc_nn=NN, use_rnn=False, bias=True, dropout_rate=0.0,
+                                   options={'masked': True}), bm, bm['delta_t'], bm['T'], bm['M'])
+    for name, (cfg, b, delta_t, T_, M) in cases.items():
+        model = build(cfg)
+        arrays = {**sd_arrays(model), **batch_arrays(b, with_M=M is not None), 'delta_t': delta_t, 'T': T_}
+        B = b['start_X'].shape[0]
+        W = torch.from_numpy(np.random.RandomState(7).standard_normal((B, cfg['hidden_size'])).astype(np.float32))
+        arrays['W'] = W.numpy()
+        for tag, with_loss in (('both', True), ('hT', False)):
+            model.train()
+            model.zero_grad()
+            hT, loss = model(b['times'], b['time_ptr'], b['X'], b['obs_idx'], delta_t, T_, b['start_X'],
+                             b['n_obs_ot'], return_path=False, get_loss=True, M=M)
+            obj = (hT * W).sum() + (loss if with_loss else 0.0)
+            obj.backward()
+            arrays[tag + '/objective'] = np.float64(obj.item())
+            for k, p in model.named_parameters():
+                # (unmasked models: hT does not depend on the readout -- no gradient there)
+                arrays[tag + '/grad/' + k] = (p.grad.numpy().copy() if p.grad is not None
+                                              else np.zeros(tuple(p.shape), dtype=np.float32))
+        arrays['train_loss'] = np.float64(loss.item())
+        arrays['train_hT'] = hT.detach().numpy()
+        save(name, cfg, arrays)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13', 'g14', 'g15']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g13', 'g14', 'g15', 'g16']
     for name in which:
         globals()[name]()

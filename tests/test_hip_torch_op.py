@@ -57,26 +57,53 @@ def test_second_backward_through_the_operator_raises():
         loss.backward()
 
 
+HT_CASES = ['g16_hT_demo', 'g16_hT_rnn', 'g16_hT_w100', 'g16_hT_masked']
+
+
 @pytest.mark.parametrize('use_op', [False, True])
-def test_gradient_through_hT_is_refused_not_dropped(use_op):
-    """The reference returns hT inside its autograd graph (models.py:414-518); the library
-    differentiates the loss only.  A loss that touches hT must raise on both routes -- round 4's
-    custom-op route received grad_hT and ignored it -- while the loss alone still trains."""
+@pytest.mark.parametrize('name', HT_CASES)
+def test_gradient_through_hT_matches_reference(name, use_op):
+    """The reference returns hT inside its autograd graph (models.py:414-518); round 4's custom-op
+    route received grad_hT and dropped it.  Now a backward pass that reaches hT runs a second pass
+    on the lockstep plan seeded with that gradient (models._hT_and_loss_grads): the gradients of
+    loss + <W, hT> and of <W, hT> alone against the reference's autograd (make_golden.py:g16), on
+    the segment plan (demo shape), the GRU jump, the shape-generic kernels and a masked model."""
+    import numpy as np
+    from golden_util import Golden
+    from hip_util import GRAD_REL_L2, grads_by_name, hip_forward, hip_model, rel_l2
+    g = Golden(name)
+    cfg = dict(g.cfg)
+    cfg['options'] = dict(cfg.get('options', {}), torch_library_op=use_op)
+    W = torch.tensor(g['W']).cuda()
+    for tag, with_loss in (('both', True), ('hT', False)):
+        m = hip_model(cfg, g.state_dict()).train()
+        hT, loss = hip_forward(m, g.batch(), g.delta_t, g.T)
+        assert hT.requires_grad
+        np.testing.assert_allclose(hT.detach().cpu().numpy(), g['train_hT'], atol=3e-5, rtol=1e-4)
+        obj = (hT * W).sum() + (loss if with_loss else 0.0)
+        assert float(obj.detach()) == pytest.approx(float(g[tag + '/objective']), rel=1e-4, abs=1e-4)
+        obj.backward()
+        got = grads_by_name(m)
+        for k, ref in g.group(tag + '/grad').items():
+            if not np.any(ref):                      # (hT does not depend on this tensor)
+                assert got[k] is None or not np.any(got[k]) or np.abs(got[k]).max() < 1e-30, k
+            else:
+                assert rel_l2(got[k], ref) < GRAD_REL_L2, (tag, k, rel_l2(got[k], ref))
+
+
+def test_hT_detached_costs_no_second_pass():
+    """The loss alone (and hT.detach()) still takes the single backward."""
     cfg = demo_cfg()
-    cfg['options'] = dict(cfg.get('options', {}), torch_library_op=use_op, device_outputs=True)
+    cfg['options'] = dict(cfg.get('options', {}), device_outputs=True)
     torch.manual_seed(0)
     m = models.NJODE(**cfg).cuda().train()
     b, meta = bs_batch(16, seed=3)
     b = to_dev(b)
-    args = (b['times'], b['time_ptr'], b['X'], b['obs_idx'], meta['dt'], meta['maturity'],
-            b['start_X'], b['n_obs_ot'])
-    hT, loss = m(*args)
-    assert hT.requires_grad                       # part of the graph, as in the reference
-    with pytest.raises(NotImplementedError, match='hT'):
-        (loss + hT.sum()).backward()
-    hT, loss = m(*args)
-    with pytest.raises(NotImplementedError, match='hT'):
-        hT.sum().backward()
-    hT, loss = m(*args)
-    (2.0 * loss + hT.detach().sum()).backward()   # detached: fine
+    calls = []
+    orig = m._grad_through_hT
+    m._grad_through_hT = lambda *a, **k: calls.append(1) or orig(*a, **k)
+    hT, loss = m(b['times'], b['time_ptr'], b['X'], b['obs_idx'], meta['dt'], meta['maturity'],
+                 b['start_X'], b['n_obs_ot'])
+    (2.0 * loss + hT.detach().sum()).backward()
+    assert not calls
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

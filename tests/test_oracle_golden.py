@@ -171,3 +171,23 @@ def test_use_rnn_with_masked_data_matches_reference():
     assert float(loss) == pytest.approx(float(g['train_loss']), rel=1e-6)
     for k, ref in g.group('grad').items():
         np.testing.assert_allclose(params[k].grad.numpy(), ref, atol=1e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['g16_hT_demo', 'g16_hT_rnn', 'g16_hT_w100', 'g16_hT_masked'])
+def test_gradient_through_hT_matches_reference(name):
+    """hT is part of the reference's autograd graph (models.py:414-518): the oracle's gradients of
+    loss + <W, hT> and of <W, hT> alone against the reference's (make_golden.py:g16)."""
+    g = Golden(name)
+    model = njode_oracle.make_oracle(g.cfg)
+    model.training = True
+    W = torch.tensor(g['W'])
+    for tag, with_loss in (('both', True), ('hT', False)):
+        params = _params(g, requires_grad=True)
+        hT, loss = _fwd(g, model, params)
+        obj = (hT * W).sum() + (loss if with_loss else 0.0)
+        obj.backward()
+        assert float(obj) == pytest.approx(float(g[tag + '/objective']), rel=1e-5, abs=1e-5)
+        for k, ref in g.group(tag + '/grad').items():
+            got = params[k].grad
+            got = np.zeros_like(ref) if got is None else got.numpy()
+            np.testing.assert_allclose(got, ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())), rtol=1e-3)
