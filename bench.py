@@ -160,7 +160,7 @@ def cpu_baseline(meta_dt, T):
             'cpu_model': _cpu_model_name(), 'host_cpu_count': os.cpu_count()}
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r04_final_pmc_summary.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r05_final_pmc_summary.json')
 
 
 def _lib_sha256():
@@ -180,7 +180,7 @@ def _lib_sha256():
 
 def measured_traffic(kernel, n_paths, dropout):
     """HBM bytes per launch of `kernel` as MEASURED on this build: profiles/
-    r03_final_pmc_summary.json is written by tools/summarize_pmc.py from `rocprofv3 --pmc
+    r05_final_pmc_summary.json is written by tools/summarize_pmc.py from `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `python bench.py` (recipe: profiles/README.md),
     and records the workload it was taken on AND the sha256 of the library it was taken with.
     Returned only when that workload is the one being benchmarked on that very library, else
