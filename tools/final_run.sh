@@ -8,7 +8,7 @@ R=${1:-r05}
 set -o pipefail
 # (the suite's verdict travels with the artifacts; profiles of a library whose suite is red are not
 # evidence: abort before they are produced)
-python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+python -m pytest tests -x -q -m gpu --durations=20 2>&1 | tail -40 | tee gpurun_out/${R}_final_pytest_tail.txt | tail -5
 rc=$?
 echo "pytest -m gpu rc=$rc" > gpurun_out/${R}_final_pytest_rc.txt
 if [ $rc -ne 0 ]; then echo "GPU suite failed (rc $rc): no profiles taken"; exit $rc; fi
