@@ -132,7 +132,8 @@ template <class CC, bool DROP> static void launch_ode_bwd_mfma(const KArgs& a, b
     if constexpr (HAS_SPLIT) {
       if (split) {
         ProfScope ps("k_ode_bwd_mixed", st);
-        k_ode_bwd_mixed<CC, DROP><<<a.n_blocks_bwd, 256, 0, st>>>(a);
+        if (a.tile_q_on) k_ode_bwd_mixed<CC, DROP, true><<<a.n_blocks_bwd, 256, 0, st>>>(a);
+        else k_ode_bwd_mixed<CC, DROP, false><<<a.n_blocks_bwd, 256, 0, st>>>(a);
         return;
       }
     }
@@ -175,7 +176,8 @@ static void launch_mfma_fwd(const KArgs& a, bool split, hipStream_t st) {
           else
             k_ode_fwd_tails<CC, DROP><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
         }
-        else k_ode_fwd_mixed<CC, DROP><<<a.n_blocks_fwd, 256, 0, st>>>(a);
+        else if (a.enc_fused) k_ode_fwd_mixed<CC, DROP, true><<<a.n_blocks_fwd, 256, 0, st>>>(a);
+        else k_ode_fwd_mixed<CC, DROP, false><<<a.n_blocks_fwd, 256, 0, st>>>(a);
         return;
       }
     }

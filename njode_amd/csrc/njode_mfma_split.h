@@ -811,10 +811,12 @@ __global__ void __launch_bounds__(64) k_ode_fwd_tails(KArgs a) {
 // of their own (higher throughput per SIMD).  T balances the two groups' finishing times,
 // so the long segments no longer set the kernel time and the bulk still runs at the
 // single-wave kernels' rate.
-template <class C, bool DROP>
+// (ENC: the NJODE_ENC_FUSED=1 form -- a kernel of its own, so that the default one keeps its
+// registers and its LDS footprint)
+template <class C, bool DROP, bool ENC = false>
 __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
-  // (behind the four-wave role's exchange images: the encoder's forward fragments, NJODE_ENC_FUSED)
-  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS + EncFwdLds<C>::FLOATS];
+  // (ENC: behind the four-wave role's exchange images, the encoder's forward fragments)
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS + (ENC ? EncFwdLds<C>::FLOATS : 0)];
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_fwd;
   const int T = (int)a.base_s[a.K + 2];
   const bool save = a.save_traj != 0;   // wave-uniform: a training forward stores checkpoints
@@ -829,16 +831,16 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
     const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
     // one-wave role on the scaled fragments (njode_ode2.h): same masks, same values to rounding
     const int nw = ((int)gridDim.x - ns) * 4;
-    if (a.enc_fused) {   // (uniform) the wave evaluates the encoder at the head of every item
+    if constexpr (ENC) {   // the wave evaluates the encoder at the head of every item
       lfp enc_img = (lfp)lds_raw + OdeFwdSplitLds<C>::FLOATS;
       EncFwdLds<C>::stage(enc_img, a.frag_enc, threadIdx.x, 256);
       __syncthreads();
       if (save) ode2_fwd_single<C, DROP, false, true, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles, enc_img);
       else ode2_fwd_single<C, DROP, false, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles, enc_img);
-      return;
+    } else {
+      if (save) ode2_fwd_single<C, DROP, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
+      else ode2_fwd_single<C, DROP, false, false>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
     }
-    if (save) ode2_fwd_single<C, DROP, false, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
-    else ode2_fwd_single<C, DROP, false, false>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
   }
 }
 template <class C> struct OdeBwdMixedLds {
@@ -846,7 +848,9 @@ template <class C> struct OdeBwdMixedLds {
   static constexpr int FLOATS = A > B ? A : B;
 };
 // one slab row per block
-template <class C, bool DROP>
+// (QUEUE: the NJODE_BWD_QUEUE=1 form -- a kernel of its own: in one kernel with the static rounds its
+// extra live values pushed the register allocation of BOTH over the edge: 256 VGPRs + 75 spilled)
+template <class C, bool DROP, bool QUEUE = false>
 __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   __shared__ __attribute__((aligned(16))) float lds_raw[OdeBwdMixedLds<C>::FLOATS];
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_blocks;
@@ -860,7 +864,7 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
   BWD_STAMP(7, (unsigned long long)((int)blockIdx.x < ns ? 1 : 0) | ((unsigned long long)T << 8) |
                    ((unsigned long long)gridDim.x << 32));
 #endif
-  if (a.tile_q_on) {   // (uniform) tile queue, persistent blocks
+  if constexpr (QUEUE) {   // tile queue, persistent blocks
     if ((int)blockIdx.x < ns) {
       ode3_bwd_split<C, DROP, true>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x, n_tiles);
     } else {
@@ -868,13 +872,13 @@ __global__ void __launch_bounds__(256, 2) k_ode_bwd_mixed(KArgs a) {
       ode3_bwd_single<C, DROP, true>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
     }
     queue_block_done(a.tile_q, gridDim.x);
-    return;
-  }
-  if ((int)blockIdx.x < ns) {
-    ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
   } else {
-    const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
-    ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
+    if ((int)blockIdx.x < ns) {
+      ode3_bwd_split<C, DROP>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T, blockIdx.x);
+    } else {
+      const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
+      ode3_bwd_single<C, DROP>(a, (lfp)lds_raw, wave, ((int)gridDim.x - ns) * 4, T, n_tiles, blockIdx.x);
+    }
   }
 }
 

@@ -805,22 +805,23 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #ifdef NJ_BWD_STAMPS
   unsigned long long t_pro = 0, t_loop = 0, t_pop = 0;
 #endif
-  for (int round = 0; QUEUE || round * n_waves < n_tiles; ++round) {
+  for (int round = 0; QUEUE ? q_rel < n_tiles : round * n_waves < n_tiles; ++round) {
 #ifdef NJ_BWD_STAMPS
     const unsigned long long tt0 = wall_clock64();
 #endif
     int rel;
     if constexpr (QUEUE) {
-      rel = round == 0 ? q_rel : n_waves + queue_value(q_raw);
-      if (rel >= n_tiles) break;
-#ifdef NJ_BWD_STAMPS
-      t_pop += wall_clock64() - tt0;
-#endif
+      rel = q_rel;
     } else {
       rel = snake_tile(round, wave, n_waves);
       if (rel >= n_tiles) continue;
     }
     const int tile = tile0 + rel;
+    // (the pop for the tile after this one: issued at the head of the tile, read at its end.  The
+    // loop is written as `while (tile in range) { ...; tile = popped; }`: the first form, `for (;;) {
+    // tile = popped; if (out of range) break; ... }`, cost this kernel 72 spilled registers and 16
+    // scratch reloads per Euler step -- same live values, another loop shape for the allocator)
+    if constexpr (QUEUE) q_raw = queue_pop_issue(a.tile_q + 1);
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
     Item<C> it;
@@ -862,9 +863,6 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     const unsigned long long tt1 = wall_clock64();
     t_pro += tt1 - tt0;
 #endif
-    // (behind the prologue's loads: vmcnt retires in order, an atomic in front of them would put its
-    // round trip on the chain order -> item -> record that the first Euler step waits for)
-    if constexpr (QUEUE) q_raw = queue_pop_issue(a.tile_q + 1);
     for (int s = nmax - 1; s >= 0; --s) {
       const float dt = s < it.n ? dt_r : 0.0f, t = t_r;
       const int sp = s > 0 ? s - 1 : 0;
@@ -975,6 +973,15 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       const int u = 4 * q + g;
       float* dst = u < C::H ? out + u : trash;
       *dst = lam[q];
+    }
+    if constexpr (QUEUE) {   // the tile after this one: popped when this one started
+#ifdef NJ_BWD_STAMPS
+      const unsigned long long tq0 = wall_clock64();
+#endif
+      q_rel = n_waves + queue_value(q_raw);
+#ifdef NJ_BWD_STAMPS
+      t_pop += wall_clock64() - tq0;
+#endif
     }
   }
 

@@ -659,11 +659,6 @@ class NJODE(torch.nn.Module):
         if not (call.flags & _lib.C_GET_LOSS):
             raise NotImplementedError('gradient through hT of a get_loss=False call')
         sched, time_ptr = call.sched_obj, call.time_ptr
-        slot_i, pinned = self._ring.acquire(sched.packed_nbytes())
-        K, nt = sched.pack_into(pinned.numpy(), time_ptr)
-        base = pinned.data_ptr()
-        cs = _lib.NjodeSchedule(K, nt, base, base + 4 * K, base + 8 * K, base + 8 * K + 4 * nt,
-                                base + 8 * K + 8 * nt)
         b0 = call.batch
         B, H = int(b0.batch_size), self.hidden_size
         gh = grad_hT.to(device=dev, dtype=torch.float32).reshape(B, H).contiguous()
@@ -672,19 +667,27 @@ class NJODE(torch.nn.Module):
                              float('inf'), b0.path_id_offset, None, None)
         flags = ((call.flags & (_lib.C_TRAIN | _lib.C_SCHED_KNOWN | _lib.C_SCHED_TAIL))
                  | _lib.C_GET_LOSS | _lib.C_SAVE_BWD | _lib.C_GEN_LOCKSTEP)
-        need = ctypes.c_size_t(0)
-        _lib.check(L.njode_workspace_bytes(ctypes.byref(call.dims), B, int(b0.n_obs), nt, K, flags,
-                                           ctypes.byref(need)))
-        slot = self._acquire_ws(need.value, dev)
+        slot_i, pinned = self._ring.acquire(sched.packed_nbytes())
+        slot = None
         try:
-            ws = slot[0]
-            hT2 = torch.empty(B, H, dtype=torch.float32, device=dev)
-            loss2 = torch.zeros(1, dtype=torch.float32, device=dev)
-            rc = L.njode_forward_f32(
-                ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(cb), ctypes.byref(cs), flags,
-                call.weight, call.p_drop, call.seed, hT2.data_ptr(), loss2.data_ptr(), None, None,
-                ws.data_ptr(), ws.numel(), stream.cuda_stream)
-            self._ring.release_after(slot_i, stream)
+            try:
+                K, nt = sched.pack_into(pinned.numpy(), time_ptr)
+                base = pinned.data_ptr()
+                cs = _lib.NjodeSchedule(K, nt, base, base + 4 * K, base + 8 * K, base + 8 * K + 4 * nt,
+                                        base + 8 * K + 8 * nt)
+                need = ctypes.c_size_t(0)
+                _lib.check(L.njode_workspace_bytes(ctypes.byref(call.dims), B, int(b0.n_obs), nt, K, flags,
+                                                   ctypes.byref(need)))
+                slot = self._acquire_ws(need.value, dev)
+                ws = slot[0]
+                hT2 = torch.empty(B, H, dtype=torch.float32, device=dev)
+                loss2 = torch.zeros(1, dtype=torch.float32, device=dev)
+                rc = L.njode_forward_f32(
+                    ctypes.byref(call.dims), self._flat.data_ptr(), ctypes.byref(cb), ctypes.byref(cs), flags,
+                    call.weight, call.p_drop, call.seed, hT2.data_ptr(), loss2.data_ptr(), None, None,
+                    ws.data_ptr(), ws.numel(), stream.cuda_stream)
+            finally:
+                self._ring.release_after(slot_i, stream)   # (the pinned schedule slot: whatever happened)
             _lib.check(rc)
             out = torch.empty_like(self._flat)
             one = torch.ones(1, dtype=torch.float32, device=dev)
@@ -694,7 +697,8 @@ class NJODE(torch.nn.Module):
                 call.weight, call.p_drop, call.seed, one.data_ptr(), out.data_ptr(), ws.data_ptr(),
                 ws.numel(), stream.cuda_stream))
         finally:
-            slot[1] = False
+            if slot is not None:
+                slot[1] = False
         return out
 
     # -- plan ahead (njode_plan_f32) --------------------------------------------------------

@@ -1,0 +1,63 @@
+"""Round-5 switches of the segment plan that are NOT the default but ship in the library
+(DESIGN.md section 4a): the backward's tile queue (`NJODE_BWD_QUEUE=1`) and the encoder evaluated
+at the head of every item inside the ODE forward (`NJODE_ENC_FUSED=1`).  Both are performance
+decisions only; a training step must give the same loss and gradient with and without them --
+the fused encoder bit for bit (same instructions, same dropout words), the queue to fp32 summation
+order (which tiles meet in one accumulator depends on timing).  The switches are read once per
+process, so every variant runs in a child process, at a batch size that takes the mixed kernels
+(more than 768 tiles of 16 items)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from hip_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(TESTS)
+
+_SNIPPET = r'''
+import sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {repo!r})
+import numpy as np, torch
+from hip_util import bs_batch, demo_cfg, hip_model
+b, meta = bs_batch(1600, seed=5)
+assert int(b['time_ptr'][-1]) > 768 * 16          # the mixed ODE kernels, both roles
+torch.manual_seed(0)
+m = hip_model(demo_cfg(dropout=0.1)).train()
+args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'], meta['maturity'],
+        b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+out = []
+for step in range(3):                              # (the queue's counters must be clean again each time)
+    m._step_counter = 11 + step
+    _, loss = m.loss_and_grad(*args)
+    out.append(np.concatenate([[float(loss)], m.flat_grad().cpu().numpy().astype(np.float64)]))
+np.save({out!r}, np.stack(out))
+'''
+
+
+def _run(tmp_path, tag, env_extra):
+    out = str(tmp_path / (tag + '.npy'))
+    env = dict(os.environ, **env_extra)
+    p = subprocess.run([sys.executable, '-c', _SNIPPET.format(tests=TESTS, repo=REPO, out=out)], env=env,
+                       cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    return np.load(out)
+
+
+def test_tile_queue_and_fused_encoder_do_not_change_the_step(tmp_path):
+    ref = _run(tmp_path, 'default', {'NJODE_BWD_QUEUE': '0', 'NJODE_ENC_FUSED': '0'})
+    assert np.isfinite(ref).all() and (np.abs(ref[:, 0]) > 0).all()
+    # the static rounds are bitwise reproducible
+    again = _run(tmp_path, 'default2', {'NJODE_BWD_QUEUE': '0', 'NJODE_ENC_FUSED': '0'})
+    assert np.array_equal(ref, again)
+    fused = _run(tmp_path, 'fused', {'NJODE_BWD_QUEUE': '0', 'NJODE_ENC_FUSED': '1'})
+    assert np.array_equal(ref, fused)              # same instructions, same dropout words
+    queue = _run(tmp_path, 'queue', {'NJODE_BWD_QUEUE': '1', 'NJODE_ENC_FUSED': '0'})
+    assert np.array_equal(queue[:, 0], ref[:, 0])  # the loss is the forward's: untouched
+    for s in range(ref.shape[0]):
+        assert rel_l2(queue[s, 1:], ref[s, 1:]) < 1e-5, (s, rel_l2(queue[s, 1:], ref[s, 1:]))
