@@ -716,9 +716,9 @@ NJ_DEV void ode3_flush(const KArgs& a, lfp lds_raw, f32x4 (&G3)[MF<C>::MTH][(MF<
 // the next tile -- longest first, the tiles are sorted -- from a counter in the workspace:
 // KArgs::tile_q[0] for the tiles [0, T) of the four-wave role, [1] for the bulk [T, n_tiles), [2]
 // counts finished blocks (the last one clears all three for the next launch; the saving forward
-// clears them once, too).  Measured (profiles/r05_bwd_fixed_costs.txt): the idle time goes (35 %
-// -> 6 % of wave time) and the launch does not get shorter, because the Euler-step loop is bound by
-// the SIMD's pipe: kept as a switch, the static rounds stay the default -- they also keep the
+// clears them once, too).  Measured (profiles/r05_bwd_fixed_costs.txt): the idle time goes (34 %
+// -> 6 % of wave time) and the launch gets 0.7 % shorter at 20 000 paths, 5 % longer at 125 000,
+// because the Euler-step loop is bound by the SIMD's pipe: kept as a switch, the static rounds stay the default -- they also keep the
 // gradient bitwise reproducible (with the queue, which tiles meet in one accumulator depends on
 // timing: equal to fp32 summation order only).
 // (the pop is issued WITHOUT a wait -- lane 0's register holds the counter's old value once the
@@ -817,11 +817,6 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
       if (rel >= n_tiles) continue;
     }
     const int tile = tile0 + rel;
-    // (the pop for the tile after this one: issued at the head of the tile, read at its end.  The
-    // loop is written as `while (tile in range) { ...; tile = popped; }`: the first form, `for (;;) {
-    // tile = popped; if (out of range) break; ... }`, cost this kernel 72 spilled registers and 16
-    // scratch reloads per Euler step -- same live values, another loop shape for the allocator)
-    if constexpr (QUEUE) q_raw = queue_pop_issue(a.tile_q + 1);
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
     Item<C> it;
@@ -863,6 +858,13 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     const unsigned long long tt1 = wall_clock64();
     t_pro += tt1 - tt0;
 #endif
+    // (the pop for the tile after this one: issued behind the prologue's loads -- vmcnt retires in
+    // order, in front of them the atomic's round trip sits on the chain order -> item -> record the
+    // first Euler step waits for: 9.0 instead of 5.4 us per tile -- and read at the tile's end.  The
+    // loop is written as `while (tile in range) { ...; tile = popped; }`: the first form, `for (;;) {
+    // tile = popped; if (out of range) break; ... }`, cost this kernel 72 spilled registers and 16
+    // scratch reloads per Euler step -- same live values, another loop shape for the allocator)
+    if constexpr (QUEUE) q_raw = queue_pop_issue(a.tile_q + 1);
     for (int s = nmax - 1; s >= 0; --s) {
       const float dt = s < it.n ? dt_r : 0.0f, t = t_r;
       const int sp = s > 0 ? s - 1 : 0;
