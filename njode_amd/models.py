@@ -345,6 +345,7 @@ class NJODE(torch.nn.Module):
         self._last_stream = None
         self._plan_pool = []
         self._plan_stream = None
+        self._last_hT_replay = None
 
     # -- reference API ----------------------------------------------------------------
     def weight_decay_step(self):
@@ -689,6 +690,7 @@ class NJODE(torch.nn.Module):
             finally:
                 self._ring.release_after(slot_i, stream)   # (the pinned schedule slot: whatever happened)
             _lib.check(rc)
+            self._last_hT_replay = hT2       # (the replayed hT: tests compare it with the call's own)
             out = torch.empty_like(self._flat)
             one = torch.ones(1, dtype=torch.float32, device=dev)
             cb.grad_hT = gh.data_ptr()

@@ -107,3 +107,40 @@ def test_hT_detached_costs_no_second_pass():
     (2.0 * loss + hT.detach().sum()).backward()
     assert not calls
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_hT_pass_replays_the_same_dropout_masks(masked):
+    """The second pass of a gradient through hT re-runs the step on the lockstep plan with the
+    call's dropout seed: with dropout ON its hT must be the call's own hT (the segment plan's tails
+    resp. the masked lockstep forward) -- masks are keyed by (seed, path, Euler step / jump time,
+    network), not by the plan -- and the gradient must be finite and repeatable."""
+    import numpy as np
+    from hip_util import hip_model
+    from njode_amd import synthetic_physionet
+    if masked:
+        nn = ((50, 'tanh'), (50, 'tanh'))
+        cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=nn, readout_nn=nn, enc_nn=nn,
+                   use_rnn=False, bias=True, dropout_rate=0.1, options={'masked': True})
+        b = synthetic_physionet.make_batch(batch_size=11, n_grid=80, n_obs_range=(4, 10), seed=6)
+        dt, T = b['delta_t'], b['T']
+    else:
+        cfg = demo_cfg(dropout=0.1)
+        b, meta = bs_batch(48, seed=8)
+        dt, T = meta['dt'], meta['maturity']
+    torch.manual_seed(0)
+    m = hip_model(cfg).train()
+    d = to_dev(b)
+    grads = []
+    for _ in range(2):
+        m._step_counter = 5
+        m.zero_grad()
+        hT, loss = m(d['times'], d['time_ptr'], d['X'], d['obs_idx'], dt, T, d['start_X'], d['n_obs_ot'],
+                     M=d.get('M'))
+        (loss + 0.37 * hT.sum()).backward()
+        np.testing.assert_allclose(m._last_hT_replay.cpu().numpy(), hT.detach().cpu().numpy(),
+                                   atol=2e-5, rtol=1e-4)
+        g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        assert torch.isfinite(g).all()
+        grads.append(g.clone())
+    assert float((grads[0] - grads[1]).norm() / grads[0].norm()) < 1e-6
