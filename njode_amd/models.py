@@ -254,6 +254,29 @@ class _NJODEFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class _NJODEhTOnlyFunction(torch.autograd.Function):
+    """hT = F(params) of a ``get_loss=False`` call: the reference's hT is differentiable there too
+    (models.py:414-518).  Nothing was saved by the forward; a backward that reaches hT replays the
+    step on the lockstep plan (``NJODE._grad_through_hT``)."""
+
+    @staticmethod
+    def forward(ctx, model, call, hT, *params):
+        ctx.model = model
+        ctx.call = call
+        ctx.set_materialize_grads(False)
+        return hT.view_as(hT)
+
+    @staticmethod
+    def backward(ctx, grad_hT):
+        model = ctx.model
+        if grad_hT is None:
+            grad_flat = torch.zeros_like(model._flat)
+        else:
+            grad_flat = model._grad_through_hT(ctx.call, grad_hT)
+        grads = [grad_flat[off:off + n].view(shape) for (off, n, shape) in model._param_slices]
+        return (None, None, None) + tuple(grads)
+
+
 # =====================================================================================
 # the model
 # =====================================================================================
@@ -657,14 +680,16 @@ class NJODE(torch.nn.Module):
         dev = self._flat.device
         if stream is None:
             stream = torch.cuda.current_stream(dev)
-        if not (call.flags & _lib.C_GET_LOSS):
-            raise NotImplementedError('gradient through hT of a get_loss=False call')
         sched, time_ptr = call.sched_obj, call.time_ptr
         b0 = call.batch
         B, H = int(b0.batch_size), self.hidden_size
         gh = grad_hT.to(device=dev, dtype=torch.float32).reshape(B, H).contiguous()
+        n_ptr, n_dummy = b0.n_obs_ot, None
+        if not n_ptr:     # (a get_loss=False call: the switched-off loss still wants a divisor)
+            n_dummy = torch.ones(B, dtype=torch.int32, device=dev)
+            n_ptr = n_dummy.data_ptr()
         # loss_batch_size = inf: every loss term (and its gradient) is scaled by 1 / inf = 0
-        cb = _lib.NjodeBatch(b0.batch_size, b0.n_obs, b0.start_X, b0.X, b0.M, b0.obs_idx, b0.n_obs_ot,
+        cb = _lib.NjodeBatch(b0.batch_size, b0.n_obs, b0.start_X, b0.X, b0.M, b0.obs_idx, n_ptr,
                              float('inf'), b0.path_id_offset, None, None)
         flags = ((call.flags & (_lib.C_TRAIN | _lib.C_SCHED_KNOWN | _lib.C_SCHED_TAIL))
                  | _lib.C_GET_LOSS | _lib.C_SAVE_BWD | _lib.C_GEN_LOCKSTEP)
@@ -821,6 +846,10 @@ class NJODE(torch.nn.Module):
         else:
             self._release_ws(call)
             loss_out = loss.reshape(()) if get_loss else 0
+            if (not get_loss and torch.is_grad_enabled()
+                    and any(p.requires_grad for p in self.parameters())):
+                self._ensure_flat()
+                hT = _NJODEhTOnlyFunction.apply(self, call, hT, *self._flat_params)
         if get_loss and not self.device_outputs:
             loss_out = loss_out.cpu()       # reference harness calls .numpy() on it
         if return_path:

@@ -144,3 +144,28 @@ def test_hT_pass_replays_the_same_dropout_masks(masked):
         assert torch.isfinite(g).all()
         grads.append(g.clone())
     assert float((grads[0] - grads[1]).norm() / grads[0].norm()) < 1e-6
+
+
+@pytest.mark.parametrize('name', HT_CASES)
+def test_hT_of_a_get_loss_false_call_is_differentiable(name):
+    """models.py:414-518: hT is in the graph whether the loss was asked for or not.  A
+    get_loss=False call saves nothing; a backward that reaches its hT replays the step (default
+    route; the custom-op route raises for such a call)."""
+    import numpy as np
+    from golden_util import Golden
+    from hip_util import GRAD_REL_L2, grads_by_name, hip_forward, hip_model, rel_l2
+    g = Golden(name)
+    W = torch.tensor(g['W']).cuda()
+    m = hip_model(g.cfg, g.state_dict()).train()
+    hT, loss = hip_forward(m, g.batch(), g.delta_t, g.T, get_loss=False)
+    assert loss == 0 and hT.requires_grad
+    (hT * W).sum().backward()
+    got = grads_by_name(m)
+    for k, ref in g.group('hT/grad').items():
+        if np.any(ref):
+            assert rel_l2(got[k], ref) < GRAD_REL_L2, (k, rel_l2(got[k], ref))
+        else:
+            assert not np.any(got[k]) or np.abs(got[k]).max() < 1e-30, k
+    with torch.no_grad():                      # (and without autograd: a plain tensor, as before)
+        hT2, _ = hip_forward(m, g.batch(), g.delta_t, g.T, get_loss=False)
+    assert not hT2.requires_grad
