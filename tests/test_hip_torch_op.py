@@ -169,3 +169,43 @@ def test_hT_of_a_get_loss_false_call_is_differentiable(name):
     with torch.no_grad():                      # (and without autograd: a plain tensor, as before)
         hT2, _ = hip_forward(m, g.batch(), g.delta_t, g.T, get_loss=False)
     assert not hT2.requires_grad
+
+
+def test_gradient_through_hT_matches_finite_differences_with_dropout_on():
+    """loss + <W, hT> with dropout 0.1 (masks fixed by the step counter): the gradient of the two
+    passes -- the call's own backward + the replay seeded with W -- against central finite
+    differences of the objective along random directions (segment plan, demo shape)."""
+    from hip_util import hip_model
+    torch.manual_seed(0)
+    m = hip_model(demo_cfg(dropout=0.1)).train()
+    b, meta = bs_batch(40, seed=9)
+    d = to_dev(b)
+    args = (d['times'], d['time_ptr'], d['X'], d['obs_idx'], meta['dt'], meta['maturity'], d['start_X'],
+            d['n_obs_ot'])
+    W = torch.randn(40, 10, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def objective():
+        m._step_counter = 5
+        hT, loss = m(*args)
+        return loss + (hT * W).sum()
+
+    m.zero_grad()
+    objective().backward()
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    flat = m.flat_parameters()
+    base = flat.clone()
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    eps = 1e-2
+    for _ in range(3):
+        v = torch.randn(flat.shape, generator=gen).to(flat.device)
+        v /= v.norm()
+        vals = []
+        for s in (+1, -1):
+            flat.copy_(base + s * eps * v)
+            with torch.no_grad():
+                vals.append(float(objective().double()))
+        flat.copy_(base)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((g * v).sum())
+        assert fd == pytest.approx(an, rel=4e-2, abs=1e-3), (fd, an)
