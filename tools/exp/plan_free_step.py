@@ -20,11 +20,12 @@ from njode_amd import _lib, models              # noqa: E402
 
 def main():
     steps, warm = 100, 20
+    n_paths = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     dev = torch.device('cuda', 0)
-    b, meta = bench.make_global_slice(0, 20000)
+    b, meta = bench.make_global_slice(0, n_paths)
     torch.manual_seed(0)
     model = models.NJODE(**bench.model_cfg(0.1)).to(dev).train()
-    model.dp_global_batch, model.dp_path_offset = 20000, 0
+    model.dp_global_batch, model.dp_path_offset = n_paths, 0
     opt = models.FusedAdam(model, lr=1e-3, weight_decay=0.0005)
     args = (b['times'], b['time_ptr'], b['X'].to(dev), b['obs_idx'].to(dev, torch.int32), meta['dt'],
             meta['maturity'], b['start_X'].to(dev), b['n_obs_ot'].to(dev, torch.int32))
