@@ -106,6 +106,10 @@ typedef struct NjodeDims {
                                    For callers whose saving forward is always followed by its backward
                                    (an autograd bridge): the readouts are evaluated once, not twice.
                                    Same value to the forward and its backward.                        */
+#define NJODE_C_PLAN_DEFER 0x800 /* (njode_plan_f32) do not launch anything now: the plan is built by the
+                                   first blocks of the ODE-forward launch of the NEXT njode_forward_f32
+                                   call this host thread makes on the same stream (one queue, no events,
+                                   no dispatches of its own: see njode_plan_f32 below)               */
 #define NJODE_C_GEN_LOCKSTEP 0x200 /* keep an unmasked loss call on the LOCKSTEP plan (both kernel
                                    families since round 5; round 4: the shape-generic one): A/B runs,
                                    tests, and the pass that differentiates through hT
@@ -197,7 +201,21 @@ int njode_workspace_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_o
  * the plan stage.  Same dims, batch arrays, schedule and call_flags (NJODE_C_PLAN_READY aside)
  * as those calls; NJODE_C_NEED_HT if the forward will be given hT != NULL.  The host schedule
  * arrays must stay valid until `stream` has executed the call (an asynchronous copy).
+ *
+ * NJODE_C_PLAN_DEFER (round 5): a second queue costs the step it runs beside two event hand-overs
+ * and a dozen small dispatches (32 us of an 880 us step at 20 000 paths).  With this flag the
+ * call only describes the job; the next njode_forward_f32 call of this host thread on the SAME
+ * stream carries it as the first blocks of its ODE-forward launch (segment plan on the matrix
+ * cores), or launches it as one kernel in front of itself when it cannot (another kernel family,
+ * another stream, the very call that consumes this plan).  Call order: njode_plan_f32(batch i+1,
+ * DEFER) ... njode_forward_f32(batch i) ... njode_forward_f32(batch i+1, PLAN_READY): stream order
+ * does the rest.  The schedule arrays are then read by the device from pinned host memory (else
+ * copied at once) and must stay valid until the stream has passed the hosting forward call.
+ * njode_plan_flush launches a job that is still pending at once (0 = nothing was pending).  Plans
+ * the single launch does not build (K >= 512 steps, NJODE_VALIDATE, lockstep plans) are built
+ * immediately, as without the flag.
  */
+int njode_plan_flush(void);
 int njode_plan_bytes(const NjodeDims* dims, int32_t batch_size, int32_t n_obs,
                      int32_t n_times, int32_t n_steps, int32_t call_flags, size_t* out);
 int njode_plan_f32(const NjodeDims* dims, const NjodeBatch* batch, const NjodeSchedule* sched,

@@ -23,6 +23,14 @@ extern "C" {
 int njode_selftest_dropout_words(uint64_t seed, uint64_t path_id, uint32_t time_key, uint32_t net,
                                  int32_t n_words, uint32_t* out_words, void* stream);
 
+/*
+ * Maintainer aid of the one-launch plan (njode_amd/csrc/njode_plan.h), active with NJODE_PLAN_STAMPS=1
+ * in the environment: the 100 MHz wall clock every plan block wrote at its stage ends during the LAST
+ * plan launch on the current device.  out[block * 8 + slot]: slot 6 = entry, slots 0..5 = end of stage
+ * 0..5.  Synchronises the device.  Returns the number of blocks copied (0: none / switched off).
+ */
+int njode_debug_plan_stamps(unsigned long long* out, int cap_blocks);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,9 +22,10 @@ C_SCHED_KNOWN, C_SCHED_TAIL = 0x20, 0x40
 C_PLAN_READY, C_NEED_HT = 0x80, 0x100
 C_ROWS_IN_FWD = 0x400       # saving forward also runs the backward's row pass (autograd bridge)
 C_GEN_LOCKSTEP = 0x200      # shape-generic kernels: unmasked loss calls stay on the lockstep plan
+C_PLAN_DEFER = 0x800        # njode_plan_f32: the plan rides in front of the next forward call's ODE-forward launch
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
-           'njode_plan_bytes', 'njode_plan_f32',
+           'njode_plan_bytes', 'njode_plan_f32', 'njode_plan_flush',
            'njode_forward_f32', 'njode_backward_f32', 'njode_backward_loss_f32',
            'njode_adam_step_f32',
            'njode_last_error', 'njode_build_info', 'njode_profile_enable',
@@ -33,7 +34,7 @@ EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
            'njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
            'njode_collate_count', 'njode_collate_fill',
            # include/njode_selftest.h
-           'njode_selftest_dropout_words')
+           'njode_selftest_dropout_words', 'njode_debug_plan_stamps')
 SDE_MODELS = {'BlackScholes': 0, 'OrnsteinUhlenbeck': 1, 'Heston': 2}
 
 
@@ -112,6 +113,8 @@ def lib():
     L.njode_plan_f32.argtypes = [C.POINTER(NjodeDims), C.POINTER(NjodeBatch),
                                  C.POINTER(NjodeSchedule), i32, vp, sz, vp]
     L.njode_plan_f32.restype = C.c_int
+    L.njode_plan_flush.argtypes = []
+    L.njode_plan_flush.restype = C.c_int
     L.njode_forward_f32.argtypes = [C.POINTER(NjodeDims), vp, C.POINTER(NjodeBatch),
                                     C.POINTER(NjodeSchedule), i32, f32, f32, u64,
                                     vp, vp, vp, vp, vp, sz, vp]
@@ -143,10 +146,11 @@ def lib():
     for name in ('njode_philox4x32_10', 'njode_generate_paths', 'njode_sample_observations',
                  'njode_collate_count', 'njode_collate_fill',
            # include/njode_selftest.h
-           'njode_selftest_dropout_words'):
+           'njode_selftest_dropout_words', 'njode_debug_plan_stamps'):
         getattr(L, name).restype = C.c_int
     L.njode_selftest_dropout_words.argtypes = [u64, u64, C.c_uint32, C.c_uint32, i32, vp, vp]
     L.njode_selftest_dropout_words.restype = C.c_int
+    L.njode_debug_plan_stamps.argtypes = [vp, C.c_int]
     _lib = L
     return L
 

@@ -141,7 +141,7 @@ def build(force=False, jobs=None, verbose=True):
                    ('njode_cfg.hip', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
                     'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                     'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
-                    'njode_mfma_lock4.h')] + [hdr]
+                    'njode_mfma_lock4.h', 'njode_plan.h')] + [hdr]
     gen_deps = [os.path.join(CSRC, n) for n in
                 ('njode_gen.hip', 'njode_gen.h', 'njode_gen_seg.h', 'njode_gen_host.h', 'njode_device.h',
                  'njode_error.h')] + [hdr]
@@ -149,7 +149,7 @@ def build(force=False, jobs=None, verbose=True):
                 ('njode_api.hip', 'njode_gen_host.h', 'njode_host.h', 'njode_kernels.h', 'njode_device.h',
                  'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                  'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
-                 'njode_mfma_lock4.h', 'njode_error.h',
+                 'njode_mfma_lock4.h', 'njode_error.h', 'njode_plan.h',
                  '_generated_cfgs.inc')] + [hdr, hdr_self]
     prod_deps = [os.path.join(CSRC, n) for n in ('njode_producer.hip', 'njode_error.h')] + [
         hdr, hdr_prod]

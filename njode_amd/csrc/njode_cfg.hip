@@ -176,6 +176,12 @@ static void launch_mfma_fwd(const KArgs& a, bool split, hipStream_t st) {
           else
             k_ode_fwd_tails<CC, DROP><<<n_tiles < 4096 ? n_tiles : 4096, 64, 0, st>>>(a);
         }
+        else if (a.plan_job) {
+          // the next batch's plan rides in front of this launch's own blocks (njode_plan.h)
+          const PlanJob job = *(const PlanJob*)a.plan_job;
+          if (a.enc_fused) k_ode_fwd_mixed_plan<CC, DROP, true><<<a.n_blocks_fwd + job.P, 256, 0, st>>>(a, job);
+          else k_ode_fwd_mixed_plan<CC, DROP, false><<<a.n_blocks_fwd + job.P, 256, 0, st>>>(a, job);
+        }
         else if (a.enc_fused) k_ode_fwd_mixed<CC, DROP, true><<<a.n_blocks_fwd, 256, 0, st>>>(a);
         else k_ode_fwd_mixed<CC, DROP, false><<<a.n_blocks_fwd, 256, 0, st>>>(a);
         return;

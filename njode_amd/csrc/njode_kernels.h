@@ -52,6 +52,9 @@ struct KArgs {
   // segment plan: the part of the plan the encoder rows do not need is built on a helper
   // stream beside them; the ODE kernel waits for this event (null: everything on one stream)
   void* plan_ready;
+  // host side only: the PlanJob (njode_plan.h) the ODE forward's launch carries in front of its own
+  // blocks -- the NEXT batch's plan, deferred to this call (njode_plan_f32 with NJODE_C_PLAN_DEFER)
+  const void* plan_job;
   // batch
   int B, n_obs;
   const float* start_X;

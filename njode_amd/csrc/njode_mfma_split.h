@@ -31,6 +31,7 @@
 #pragma once
 #include "njode_mfma.h"
 #include "njode_ode2.h"
+#include "njode_plan.h"
 
 namespace njode {
 
@@ -813,26 +814,30 @@ __global__ void __launch_bounds__(64) k_ode_fwd_tails(KArgs a) {
 // single-wave kernels' rate.
 // (ENC: the NJODE_ENC_FUSED=1 form -- a kernel of its own, so that the default one keeps its
 // registers and its LDS footprint)
-template <class C, bool DROP, bool ENC = false>
-__global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
-  // (ENC: behind the four-wave role's exchange images, the encoder's forward fragments)
-  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdSplitLds<C>::FLOATS + (ENC ? EncFwdLds<C>::FLOATS : 0)];
+// (PLAN: the launch carries the NEXT batch's plan in front of its own blocks -- njode_plan.h; a
+// kernel of its own, so that launches without a job keep their argument list and their registers)
+template <class C, bool ENC, bool PLAN> struct OdeFwdMixedLds {
+  static constexpr int OWN = OdeFwdSplitLds<C>::FLOATS + (ENC ? EncFwdLds<C>::FLOATS : 0);
+  static constexpr int FLOATS = (PLAN && PLAN_LDS_INTS > OWN) ? PLAN_LDS_INTS : OWN;
+};
+template <class C, bool DROP, bool ENC, bool PLAN>
+__device__ __forceinline__ void ode_fwd_mixed_body(const KArgs& a, lfp lds_raw, int bid, int nblocks) {
   const int n_tiles = (a.n_obs + 15) / 16, ns = a.n_split_fwd;
   const int T = (int)a.base_s[a.K + 2];
   const bool save = a.save_traj != 0;   // wave-uniform: a training forward stores checkpoints
                                          // and activations, an evaluation forward nothing
   // (the backward's tile queue starts from zero: its last block clears it again, this covers the
   // very first launch on a fresh workspace)
-  if (save && blockIdx.x == 0 && threadIdx.x == 0) { a.tile_q[0] = 0; a.tile_q[1] = 0; a.tile_q[2] = 0; }
-  if ((int)blockIdx.x < ns) {
-    if (save) ode_fwd_split<C, DROP, false, true>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
-    else ode_fwd_split<C, DROP, false, false>(a, (lfp)lds_raw, blockIdx.x, ns, 0, T);
+  if (save && bid == 0 && threadIdx.x == 0) { a.tile_q[0] = 0; a.tile_q[1] = 0; a.tile_q[2] = 0; }
+  if (bid < ns) {
+    if (save) ode_fwd_split<C, DROP, false, true>(a, lds_raw, bid, ns, 0, T);
+    else ode_fwd_split<C, DROP, false, false>(a, lds_raw, bid, ns, 0, T);
   } else {
-    const int wave = ((int)blockIdx.x - ns) * 4 + uniform(threadIdx.x >> 6);
+    const int wave = (bid - ns) * 4 + uniform(threadIdx.x >> 6);
     // one-wave role on the scaled fragments (njode_ode2.h): same masks, same values to rounding
-    const int nw = ((int)gridDim.x - ns) * 4;
+    const int nw = (nblocks - ns) * 4;
     if constexpr (ENC) {   // the wave evaluates the encoder at the head of every item
-      lfp enc_img = (lfp)lds_raw + OdeFwdSplitLds<C>::FLOATS;
+      lfp enc_img = lds_raw + OdeFwdSplitLds<C>::FLOATS;
       EncFwdLds<C>::stage(enc_img, a.frag_enc, threadIdx.x, 256);
       __syncthreads();
       if (save) ode2_fwd_single<C, DROP, false, true, true>(a, threadIdx.x & 63, wave, nw, T, n_tiles, enc_img);
@@ -842,6 +847,21 @@ __global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
       else ode2_fwd_single<C, DROP, false, false>(a, threadIdx.x & 63, wave, nw, T, n_tiles);
     }
   }
+}
+template <class C, bool DROP, bool ENC = false>
+__global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed(KArgs a) {
+  // (ENC: behind the four-wave role's exchange images, the encoder's forward fragments)
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdMixedLds<C, ENC, false>::FLOATS];
+  ode_fwd_mixed_body<C, DROP, ENC, false>(a, (lfp)lds_raw, blockIdx.x, gridDim.x);
+}
+template <class C, bool DROP, bool ENC = false>
+__global__ void __launch_bounds__(256, 2) k_ode_fwd_mixed_plan(KArgs a, PlanJob job) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[OdeFwdMixedLds<C, ENC, true>::FLOATS];
+  if ((int)blockIdx.x < job.P) {
+    plan_grid_body(job, blockIdx.x, (int*)lds_raw);
+    return;
+  }
+  ode_fwd_mixed_body<C, DROP, ENC, true>(a, (lfp)lds_raw, (int)blockIdx.x - job.P, (int)gridDim.x - job.P);
 }
 template <class C> struct OdeBwdMixedLds {
   static constexpr int A = OdeBwdActLds<C>::FLOATS, B = OdeBwdSplitLds<C>::FLOATS;

@@ -205,9 +205,15 @@ class _Plan:
     queued) and the version counter ``obs_idx`` had: a call only takes a plan of the very same,
     unmodified objects."""
     __slots__ = ('buf', 'done', 'flags', 'sizes', 'keep', 'pool', 'obs_idx', 'time_ptr',
-                 'obs_version', 'taken')
+                 'obs_version', 'taken', 'pending')
 
     def __del__(self):
+        # a deferred plan nobody has launched yet must not outlive its buffer
+        if getattr(self, 'pending', False):
+            try:
+                _lib.lib().njode_plan_flush()
+            except Exception:
+                pass
         pool, buf = getattr(self, 'pool', None), getattr(self, 'buf', None)
         if pool is not None and buf is not None and len(pool) < 4:
             pool.append(buf)
@@ -368,6 +374,8 @@ class NJODE(torch.nn.Module):
         self._last_stream = None
         self._plan_pool = []
         self._plan_stream = None
+        self._deferred_slots = []    # pinned schedule slots of plans whose launch is deferred
+        self._deferred_plans = []    # ... and the plans themselves (their buffers stay alive until launched)
         self._last_hT_replay = None
 
     # -- reference API ----------------------------------------------------------------
@@ -616,7 +624,8 @@ class NJODE(torch.nn.Module):
         if plan is not None:
             cb.plan = plan.buf.data_ptr()
             flags |= _lib.C_PLAN_READY | (plan.flags & _lib.C_NEED_HT)
-            (stream if stream is not None else torch.cuda.current_stream(dev)).wait_event(plan.done)
+            if plan.done is not None:    # (a deferred plan is on this very stream: stream order)
+                (stream if stream is not None else torch.cuda.current_stream(dev)).wait_event(plan.done)
             keep.append(plan)
         need = ctypes.c_size_t(0)
         _lib.check(L.njode_workspace_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
@@ -646,8 +655,19 @@ class NJODE(torch.nn.Module):
             path_h.data_ptr() if path_h is not None else None,
             path_y.data_ptr() if path_y is not None else None,
             call.ws.data_ptr(), call.ws.numel(), stream.cuda_stream)
-        self._ring.release_after(slot_i, stream)
+        self._release_slots(slot_i, stream)
         _lib.check(rc)
+
+    def _release_slots(self, slot_i, stream):
+        """After an ``njode_forward_f32`` call: its pinned schedule slot is free once ``stream`` has
+        passed it -- and so are the slots of deferred plans, which that call hosted or launched."""
+        self._ring.release_after(slot_i, stream)
+        for p in self._deferred_slots:
+            self._ring.release_with(p, slot_i)
+        del self._deferred_slots[:]
+        for pl in self._deferred_plans:
+            pl.pending = False
+        del self._deferred_plans[:]
 
     def _run_backward(self, call, grad_loss, grad_flat, loss=None, stream=None):
         """``loss`` given: the fused step's backward, which may also produce the loss
@@ -713,7 +733,7 @@ class NJODE(torch.nn.Module):
                     call.weight, call.p_drop, call.seed, hT2.data_ptr(), loss2.data_ptr(), None, None,
                     ws.data_ptr(), ws.numel(), stream.cuda_stream)
             finally:
-                self._ring.release_after(slot_i, stream)   # (the pinned schedule slot: whatever happened)
+                self._release_slots(slot_i, stream)   # (the pinned schedule slot: whatever happened)
             _lib.check(rc)
             self._last_hT_replay = hT2       # (the replayed hT: tests compare it with the call's own)
             out = torch.empty_like(self._flat)
@@ -729,8 +749,21 @@ class NJODE(torch.nn.Module):
         return out
 
     # -- plan ahead (njode_plan_f32) --------------------------------------------------------
+    def plan_defer_ok(self, n_obs):
+        """Whether ``prefetch_plan`` defers a plan of ``n_obs`` observation rows into the next
+        forward call's ODE-forward launch (``NJODE_C_PLAN_DEFER``) instead of building it on a helper
+        stream.  Inside that launch the plan blocks share the memory system with a kernel that
+        streams ~2 TB/s and take 2 - 3x their time on an idle chip: up to ~32 000 rows (3 000 paths of
+        the demo datasets) the plan ends well before the forward does -- B = 100: 0.250 -> 0.235 ms
+        per step, B = 1 000: 0.332 -> 0.316; at 20 000 paths it would outlast it (0.37 against 0.23 ms),
+        so large batches keep the helper stream (``profiles/r05_plan_in_forward.txt``).
+        ``NJODE_PLAN_DEFER=0`` switches it off, ``NJODE_PLAN_DEFER_MAX`` moves the limit."""
+        if self.masked or self.use_rnn or os.environ.get('NJODE_PLAN_DEFER', '1') == '0':
+            return False
+        return 0 < n_obs <= int(os.environ.get('NJODE_PLAN_DEFER_MAX', '32768'))
+
     def prefetch_plan(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
-                      M=None, need_hT=None):
+                      M=None, need_hT=None, defer=None):
         """Build the execution plan of a coming ``loss_and_grad`` / training ``forward`` call
         for this batch NOW, on a helper stream, beside whatever the current stream is running
         (``include/njode_hip.h``: ``njode_plan_f32``).  The plan depends on the batch and the
@@ -740,8 +773,15 @@ class NJODE(torch.nn.Module):
         step on batch i.  Returns a handle that may be passed to that call as ``plan=``
         (otherwise the call finds it by the identity of ``obs_idx`` and ``time_ptr``).
         ``need_hT``: the coming call returns hT.  Default True -- ``forward`` always does;
-        ``loss_and_grad`` of an unmasked model does not and simply ignores the tail order."""
+        ``loss_and_grad`` of an unmasked model does not and simply ignores the tail order.
+        ``defer`` (round 5; default: on for unmasked models without ``use_rnn``, ``NJODE_PLAN_DEFER=0``
+        turns it off): no helper stream and no events -- the plan is built by the first blocks of the
+        ODE-forward launch of the NEXT forward call on the current stream (``NJODE_C_PLAN_DEFER``,
+        ``include/njode_hip.h``), i.e. of the step on batch i when this is called for batch i+1
+        right before it; the batch's arrays must be ready on the current stream."""
         need_hT = True if need_hT is None else bool(need_hT)
+        if defer is None:
+            defer = self.plan_defer_ok(int(np.asarray(time_ptr)[-1]))
         dims, cb, cs, flags, keep, slot_i, (B, n_obs, nt, K) = self._make_call(
             times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot, False, True, False, M,
             save_bwd=True, plan_only=True)
@@ -759,23 +799,37 @@ class NJODE(torch.nn.Module):
                 break
         if buf is None:
             buf = torch.empty(int(need.value * 1.25) + 4096, dtype=torch.uint8, device=dev)
-        if self._plan_stream is None:
-            self._plan_stream = torch.cuda.Stream(device=dev)
-        side = self._plan_stream
-        side.wait_stream(torch.cuda.current_stream(dev))   # the batch's arrays are ready by now
-        # (the library call, the ring and the event all take the stream explicitly: no
-        # `with torch.cuda.stream(side)` -- entering and leaving it costs ~15 us of host time)
-        rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs), flags,
-                              buf.data_ptr(), buf.numel(), side.cuda_stream)
-        self._ring.release_after(slot_i, side)
-        _lib.check(rc)
-        done = torch.cuda.Event()
-        done.record(side)
+        if defer:
+            # one queue: the job is only described now; the next forward call on this stream carries
+            # it (or launches it in front of itself).  Its pinned schedule slot stays held until then.
+            cur = torch.cuda.current_stream(dev)
+            self._ring.hold(slot_i)
+            self._deferred_slots.append(slot_i)
+            rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs),
+                                  flags | _lib.C_PLAN_DEFER, buf.data_ptr(), buf.numel(), cur.cuda_stream)
+            _lib.check(rc)
+            done = None
+        else:
+            if self._plan_stream is None:
+                self._plan_stream = torch.cuda.Stream(device=dev)
+            side = self._plan_stream
+            side.wait_stream(torch.cuda.current_stream(dev))   # the batch's arrays are ready by now
+            # (the library call, the ring and the event all take the stream explicitly: no
+            # `with torch.cuda.stream(side)` -- entering and leaving it costs ~15 us of host time)
+            rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs), flags,
+                                  buf.data_ptr(), buf.numel(), side.cuda_stream)
+            self._ring.release_after(slot_i, side)
+            _lib.check(rc)
+            done = torch.cuda.Event()
+            done.record(side)
         plan = _Plan()
         plan.buf, plan.done, plan.flags, plan.sizes, plan.keep = buf, done, flags, (B, n_obs, nt, K), keep
         plan.pool = self._plan_pool
         plan.obs_idx, plan.time_ptr, plan.taken = obs_idx, time_ptr, False
         plan.obs_version = getattr(obs_idx, '_version', 0)
+        plan.pending = bool(defer)
+        if defer:
+            self._deferred_plans.append(plan)
         self._plans.append(plan)
         # plans nobody picks up (a prefetched batch that is then never stepped on) must not pile
         # up: keep the four newest

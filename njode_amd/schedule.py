@@ -112,10 +112,13 @@ class PinnedRing:
         self.slots = [None] * slots
         self.events = [None] * slots
         self.next = 0
+        self.held = set()
 
     def acquire(self, nbytes):
         i = self.next
-        self.next = (self.next + 1) % len(self.slots)
+        while i in self.held and len(self.held) < len(self.slots):
+            i = (i + 1) % len(self.slots)
+        self.next = (i + 1) % len(self.slots)
         ev = self.events[i]
         if ev is not None:
             ev.synchronize()
@@ -126,7 +129,19 @@ class PinnedRing:
             self.slots[i] = t
         return i, t
 
+    def hold(self, i):
+        """Slot ``i`` is read by work that is not enqueued yet (a deferred plan): ``acquire``
+        passes it over until ``release_with`` / ``release_after`` frees it."""
+        self.held.add(i)
+
+    def release_with(self, i, j):
+        """Slot ``i`` is free when slot ``j`` is: both were read by the same enqueued call (they
+        share ``j``'s event; recording it again for either only moves the guard later)."""
+        self.held.discard(i)
+        self.events[i] = self.events[j]
+
     def release_after(self, i, stream):
+        self.held.discard(i)
         ev = self.events[i]
         if ev is None:
             ev = torch.cuda.Event()

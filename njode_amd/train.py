@@ -211,8 +211,11 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             # kernels queued ahead delay the step's own; B >= 4 096: the plan (~0.1 ms) hides
             # beside the ODE kernels (bench.py: 1.19 -> 1.14 ms at 20 000 paths).
             n_next = len(nxt[2]) if nxt is not None else 0
+            # (round 5: up to ~32 000 rows the plan rides inside this step's ODE-forward launch --
+            # no helper stream, it pays at every size: NJODE.plan_defer_ok)
             if plan_ahead and fused and n_next >= max(plan_ahead_min, 1) and \
-                    (n_next <= 512 or n_next >= 4096):
+                    (n_next <= 512 or n_next >= 4096 or
+                     model.plan_defer_ok(int(nxt[3]['time_ptr'][-1]))):
                 dn = nxt[3]
                 model.prefetch_plan(dn['times'], dn['time_ptr'], dn['X'], dn['obs_idx'], delta_t, T,
                                     dn['start_X'], dn['n_obs_ot'], need_hT=False)

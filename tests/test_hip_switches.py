@@ -61,3 +61,65 @@ def test_tile_queue_and_fused_encoder_do_not_change_the_step(tmp_path):
     assert np.array_equal(queue[:, 0], ref[:, 0])  # the loss is the forward's: untouched
     for s in range(ref.shape[0]):
         assert rel_l2(queue[s, 1:], ref[s, 1:]) < 1e-5, (s, rel_l2(queue[s, 1:], ref[s, 1:]))
+
+
+# ---- the one-launch plan (njode_plan.h) ---------------------------------------------------------
+# Same arrays as the multi-launch plan (row times, links, the STABLE order by length, the trajectory
+# layout, the split points): the tiles are the same rows in the same lanes, so with the static rounds
+# a training step and a prediction call give the same bits whether the plan is
+#   defer   built by the first blocks of the previous step's ODE-forward launch (the default of
+#           prefetch_plan: NJODE_C_PLAN_DEFER), or by k_plan_grid in line when nothing was prefetched,
+#   side    built on the helper stream (NJODE_PLAN_DEFER=0), in line by k_plan_grid for small plans,
+#   legacy  built by the multi-launch kernels everywhere (NJODE_PLAN_GRID=0).
+_SNIPPET_PLAN = r'''
+import sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {repo!r})
+import numpy as np, torch
+from hip_util import bs_batch, demo_cfg, hip_model
+out = []
+def dev_args(b, meta):
+    return (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'], meta['maturity'],
+            b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+for B, seed, perc in ((7, 3, 0.1), (100, 5, 0.1), (150, 6, 0.02), (1000, 7, 0.1), (1600, 8, 0.1), (6000, 9, 0.1)):
+    batches = [dev_args(*bs_batch(B, seed=seed + 100 * i, obs_perc=perc)) for i in range(2)]   # (0.02: paths without a row)
+    torch.manual_seed(0)
+    m = hip_model(demo_cfg(dropout=0.1)).train()
+    m.prefetch_plan(*batches[0], need_hT=False)
+    for step in range(4):
+        m._step_counter = 11 + step
+        m.prefetch_plan(*batches[(step + 1) % 2], need_hT=False)      # the next step's plan, ahead
+        _, loss = m.loss_and_grad(*batches[step % 2])
+        out.append(np.concatenate([[float(loss)], m.flat_grad().cpu().numpy().astype(np.float64)]))
+    m._plans.clear()
+    m._step_counter = 21
+    _, loss = m.loss_and_grad(*batches[1])                            # nothing prefetched: plan in line
+    out.append(np.concatenate([[float(loss)], m.flat_grad().cpu().numpy().astype(np.float64)]))
+    m.eval()
+    with torch.no_grad():
+        m.prefetch_plan(*batches[0])                                  # with the tail order (hT)
+        hT1, loss1 = m(*batches[1])                                   # ... hosted by another batch's call
+        hT0, loss0 = m(*batches[0])
+    for hT, loss in ((hT1, loss1), (hT0, loss0)):
+        out.append(np.concatenate([[float(loss)], hT.cpu().numpy().astype(np.float64).ravel()]))
+np.save({out!r}, np.concatenate(out))
+'''
+
+
+def test_one_launch_plan_is_the_same_plan(tmp_path):
+    res = {}
+    big = {'NJODE_PLAN_DEFER': '1', 'NJODE_PLAN_DEFER_MAX': '1000000'}   # (also the 60 000-row batch)
+    for tag, env in (('defer', dict(big, NJODE_PLAN_GRID='1')),
+                     ('default', {}),
+                     ('side', {'NJODE_PLAN_DEFER': '0', 'NJODE_PLAN_GRID': '1'}),
+                     ('legacy', {'NJODE_PLAN_DEFER': '0', 'NJODE_PLAN_GRID': '0'}),
+                     ('defer_p3', dict(big, NJODE_PLAN_BLOCKS='3')),
+                     ('defer_p200', dict(big, NJODE_PLAN_BLOCKS='200'))):
+        out = str(tmp_path / (tag + '.npy'))
+        p = subprocess.run([sys.executable, '-c', _SNIPPET_PLAN.format(tests=TESTS, repo=REPO, out=out)],
+                           env=dict(os.environ, **env), cwd=REPO, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:]
+        res[tag] = np.load(out)
+    assert np.isfinite(res['legacy']).all()
+    for tag in res:
+        assert np.array_equal(res[tag], res['legacy']), tag
