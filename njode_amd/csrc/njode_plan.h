@@ -60,20 +60,34 @@ struct PlanJob {
   SplitCfg sc;
 };
 
-// Barrier among the P plan blocks.  Every thread publishes its global stores (agent-scope fence)
-// before the workgroup barrier, thread 0 counts the block in and waits for the others, every thread
-// drops what its caches hold afterwards.
+// What the plan blocks hand to each other between two stages goes through pld / pst: agent-scope
+// relaxed atomics, i.e. loads and stores with the sc1 bit -- coherent across the eight XCDs' L2s access
+// by access.  The textbook alternative (plain accesses + __threadfence() around the barrier) makes
+// every thread write back and invalidate its XCD's whole L2 at every barrier: with the ODE forward
+// streaming its step records beside the plan that took the plan 370 us at 20 000 paths (137 alone) and the
+// kernels beside it up to twice their time (profiles/r05_plan_in_forward.txt).  COH = false (one
+// plan block): plain accesses.
+template <bool COH, class T> __device__ __forceinline__ T pld(const T* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH, class T> __device__ __forceinline__ void pst(T* p, T v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+// Barrier among the P plan blocks: every wave waits for its own stores (write-through: acknowledged at
+// the coherence point), the workgroup meets, thread 0 counts the block in and waits for the others.
+// No cache-wide operation.
 __device__ inline void plan_sync(unsigned* ctr, unsigned base, int P) {
   if (P > 1) {
-    __threadfence();
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
     __syncthreads();
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      while ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - base) < P)
-        __builtin_amdgcn_s_sleep(1);
+      __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base) < P)
+        __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
-    __threadfence();
   } else {
     __syncthreads();
   }
@@ -83,7 +97,7 @@ __device__ inline void plan_sync(unsigned* ctr, unsigned base, int P) {
 // cnt_s = #{len > s}; base_s = exclusive prefix sum of cnt; base16_s the same with every count rounded
 // up to a whole tile; base_s[K+1], [K+2] = split points T of the mixed ODE backward / forward.
 // lds: SPLIT_KMAX + 1 + 64 ints when K <= SPLIT_KMAX is to take the workgroup scans (lds_cnt), else unused.
-template <int NT>
+template <int NT, bool COH = false>
 __device__ inline void traj_layout_body(const int* len_hist, int n_obs, int K, long long* base_s,
                                         long long* base16_s, const SplitCfg& sc, int* lds, bool lds_cnt) {
   constexpr int NWV = NT / 64;
@@ -115,7 +129,7 @@ __device__ inline void traj_layout_body(const int* len_hist, int n_obs, int K, l
   // Both as workgroup scans: thread t owns the chunk [t * ch, (t + 1) * ch).
   if (lds_cnt) {
     const int ch = (K + 1 + NT - 1) / NT;
-    for (int s = tid; s <= K; s += NT) cnt[s] = len_hist[s];
+    for (int s = tid; s <= K; s += NT) cnt[s] = pld<COH>(len_hist + s);
     __syncthreads();
     {   // suffix: scan the reversed array (thread t owns the reversed chunk)
       long long loc = 0;
@@ -265,7 +279,8 @@ __device__ inline void traj_layout_body(const int* len_hist, int n_obs, int K, l
 }
 
 // One plan block (PLAN_THREADS threads) of P.  lds: PLAN_LDS_INTS ints.
-__device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
+template <bool COH>
+__device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
   constexpr int NT = PLAN_THREADS;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int P = j.P, n = j.n, B = j.B, K = j.K, nt = j.n_times;
@@ -282,21 +297,28 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
   // ---- stage 0: schedule into place (block 0, from the pinned host copy), dense = -1, histogram = 0
   if (pb == 0) {
     if (j.sched_src)
-      for (int i = tid; i < j.sched_ints; i += NT) j.sched_dst[i] = j.sched_src[i];
-    for (int s = tid; s < nkeys; s += NT) j.len_hist[s] = 0;
+      for (int i = tid; i < j.sched_ints; i += NT) pst<COH>(j.sched_dst + i, j.sched_src[i]);
+    for (int s = tid; s < nkeys; s += NT) pst<COH>(j.len_hist + s, 0);
   }
   {
     const size_t cells = (size_t)nt * B;
-    int4* d4 = (int4*)j.dense;                 // (256-byte aligned region)
-    const size_t c4 = cells >> 2;
-    for (size_t i = gtid; i < c4; i += gthreads) d4[i] = make_int4(-1, -1, -1, -1);
-    for (size_t i = (c4 << 2) + gtid; i < cells; i += gthreads) j.dense[i] = -1;
+    if constexpr (COH) {
+      long long* d2 = (long long*)j.dense;     // (256-byte aligned region)
+      const size_t c2 = cells >> 1;
+      for (size_t i = gtid; i < c2; i += gthreads) pst<COH>(d2 + i, -1ll);
+      if ((cells & 1) && gtid == 0) pst<COH>(j.dense + cells - 1, -1);
+    } else {
+      int4* d4 = (int4*)j.dense;
+      const size_t c4 = cells >> 2;
+      for (size_t i = gtid; i < c4; i += gthreads) d4[i] = make_int4(-1, -1, -1, -1);
+      for (size_t i = (c4 << 2) + gtid; i < cells; i += gthreads) j.dense[i] = -1;
+    }
   }
   plan_sync(j.sync + 0, j.sync_base, P);
   stamp(0);
   // ---- stage 1: time slice of every row (binary search over the CSR offsets, held in LDS), scatter
   // into the dense [time slice][path] matrix
-  for (int i = tid; i <= nt; i += NT) lds[i] = j.time_ptr[i];
+  for (int i = tid; i <= nt; i += NT) lds[i] = pld<COH>(j.time_ptr + i);
   __syncthreads();
   // (a wave takes 256 consecutive rows at a time, lane l the rows base + 64 u + l: the rows are sorted
   // by time, so the slice of u + 1 is found from the slice of u by stepping, not by searching again)
@@ -322,7 +344,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
       if (r < n) {
         while (lo + 1 < nt && lds[lo + 1] <= r) ++lo;
         j.t_of_row[r] = lo;
-        j.dense[(size_t)lo * B + path[u]] = r;
+        pst<COH>(j.dense + (size_t)lo * B + path[u], r);
       }
     }
   }
@@ -333,7 +355,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
   int* hist = lds;
   int* kj = lds + PLAN_KEYS;
   for (int s = tid; s < nkeys; s += NT) hist[s] = 0;
-  for (int i = tid; i < nt; i += NT) kj[i] = j.k_jump[i];
+  for (int i = tid; i < nt; i += NT) kj[i] = pld<COH>(j.k_jump + i);
   __syncthreads();
   for (int b = gtid; b < B; b += gthreads) {
     int prev = -1, kprev = 0;
@@ -341,7 +363,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
     for (int i0 = 0; i0 < nt; i0 += CH) {
       int rr[CH];
 #pragma unroll
-      for (int q = 0; q < CH; ++q) rr[q] = i0 + q < nt ? j.dense[(size_t)(i0 + q) * B + b] : -1;
+      for (int q = 0; q < CH; ++q) rr[q] = i0 + q < nt ? pld<COH>(j.dense + (size_t)(i0 + q) * B + b) : -1;
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         const int r = rr[q];
@@ -352,7 +374,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
         if (prev >= 0) j.item_next[prev] = r; else j.first_row[b] = r;
         j.item_kbeg[r] = kprev;
         j.item_len[r] = len;
-        j.sort_key[r] = (unsigned)(K - len);   // ascending key == descending length
+        pst<COH>(j.sort_key + r, (unsigned)(K - len));   // ascending key == descending length
         if (len >= 0 && len <= K) atomicAdd(&hist[len], 1);
         prev = r;
         kprev = kend;
@@ -379,9 +401,9 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
       const int r0 = wb << j.cs_shift;
       for (int it = 0; it < rounds; ++it) {    // (integer LDS atomics on the wave's own counters)
         const int r = r0 + it * 64 + lane;
-        if (r < n) atomicAdd(&cnt[min((int)j.sort_key[r], nkeys - 1)], 1);
+        if (r < n) atomicAdd(&cnt[min((int)pld<COH>(j.sort_key + r), nkeys - 1)], 1);
       }
-      for (int s = lane; s < nkeys; s += 64) j.cs_tab[(size_t)s * nwb + wb] = cnt[s];
+      for (int s = lane; s < nkeys; s += 64) pst<COH>(j.cs_tab + (size_t)s * nwb + wb, cnt[s]);
     }
   }
   if (layout_block) {
@@ -389,12 +411,12 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
       // the layout only needs the histogram and nobody in this launch reads it: this block counts
       // itself in at the two barriers the others still need and works through their stages 3 - 5
       if (tid == 0) {
-        __hip_atomic_fetch_add(j.sync + 3, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(j.sync + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(j.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(j.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();                           // (P == 1: the counters above live in the same LDS)
-    traj_layout_body<NT>(j.len_hist, n, K, j.base_s, j.base16_s, j.sc, lds, true);
+    traj_layout_body<NT, COH>(j.len_hist, n, K, j.base_s, j.base16_s, j.sc, lds, true);
     if (P > 1) {
       stamp(3);
       stamp(4);
@@ -413,7 +435,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
     int carry = 0;
     for (int k0 = 0; k0 < nkeys; k0 += NT) {
       const int key = k0 + tid;
-      const int v = key < nkeys ? j.len_hist[K - key] : 0;
+      const int v = key < nkeys ? pld<COH>(j.len_hist + K - key) : 0;
       int incl = v;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -434,11 +456,11 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
         int* row = j.cs_tab + (size_t)key * nwb;
         int v[PLAN_SCAN_CHUNKS];
 #pragma unroll
-        for (int q = 0; q < PLAN_SCAN_CHUNKS; ++q) v[q] = q < nwb ? row[q] : 0;
+        for (int q = 0; q < PLAN_SCAN_CHUNKS; ++q) v[q] = q < nwb ? pld<COH>(row + q) : 0;
         int run = kb[key];
 #pragma unroll
         for (int q = 0; q < PLAN_SCAN_CHUNKS; ++q) {
-          if (q < nwb) row[q] = run;
+          if (q < nwb) pst<COH>(row + q, run);
           run += v[q];
         }
       }
@@ -449,7 +471,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
 #pragma unroll
         for (int q = 0; q < PLAN_SCAN_CHUNKS; ++q) {
           const int i = q * 64 + lane;
-          v[q] = i < nwb ? row[i] : 0;
+          v[q] = i < nwb ? pld<COH>(row + i) : 0;
         }
         int run = kb[key];
 #pragma unroll
@@ -462,7 +484,7 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
               const int up = __shfl_up(incl, o);
               if (lane >= o) incl += up;
             }
-            if (i < nwb) row[i] = run + incl - v[q];
+            if (i < nwb) pst<COH>(row + i, run + incl - v[q]);
             run += __shfl(incl, 63);
           }
         }
@@ -479,12 +501,12 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
     int key_bits = 1;
     while ((1 << key_bits) < nkeys) ++key_bits;
     for (int wb = gw; wb < nwb; wb += wwaves) {
-      for (int s = lane; s < nkeys; s += 64) cnt[s] = j.cs_tab[(size_t)s * nwb + wb];
+      for (int s = lane; s < nkeys; s += 64) cnt[s] = pld<COH>(j.cs_tab + (size_t)s * nwb + wb);
       const int r0 = wb << j.cs_shift;
       for (int it = 0; it < rounds; ++it) {
         const int r = r0 + it * 64 + lane;
         const bool ok = r < n;
-        const int k = ok ? min((int)j.sort_key[r], nkeys - 1) : -1;
+        const int k = ok ? min((int)pld<COH>(j.sort_key + r), nkeys - 1) : -1;
         // lanes with the same key: one ballot per key bit instead of one round per distinct key
         unsigned long long same = __ballot(ok);
         for (int bit = 0; bit < key_bits; ++bit) {
@@ -500,6 +522,10 @@ __device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
     }
   }
   stamp(5);
+}
+__device__ inline void plan_grid_body(const PlanJob& j, int pb, int* lds) {
+  if (j.P > 1) plan_grid_stages<true>(j, pb, lds);
+  else plan_grid_stages<false>(j, pb, lds);
 }
 
 }  // namespace njode

@@ -753,14 +753,15 @@ class NJODE(torch.nn.Module):
         """Whether ``prefetch_plan`` defers a plan of ``n_obs`` observation rows into the next
         forward call's ODE-forward launch (``NJODE_C_PLAN_DEFER``) instead of building it on a helper
         stream.  Inside that launch the plan blocks share the memory system with a kernel that
-        streams ~2 TB/s and take 2 - 3x their time on an idle chip: up to ~32 000 rows (3 000 paths of
-        the demo datasets) the plan ends well before the forward does -- B = 100: 0.250 -> 0.235 ms
-        per step, B = 1 000: 0.332 -> 0.316; at 20 000 paths it would outlast it (0.37 against 0.23 ms),
-        so large batches keep the helper stream (``profiles/r05_plan_in_forward.txt``).
-        ``NJODE_PLAN_DEFER=0`` switches it off, ``NJODE_PLAN_DEFER_MAX`` moves the limit."""
+        streams ~2 TB/s and take about twice their time on an idle chip; as long as they end before the
+        forward does the step only pays their share of its slots: B = 100 0.250 -> 0.235 ms per step,
+        B = 1 000 0.332 -> 0.317, 20 000 paths 0.877 -> 0.85; from 50 000 paths on the plan outlasts the
+        forward (1.93 -> 1.95 ms; 125 000: 4.79 -> 4.85), so very large batches keep the helper stream
+        (``profiles/r05_plan_in_forward.txt``).  ``NJODE_PLAN_DEFER=0`` switches it off,
+        ``NJODE_PLAN_DEFER_MAX`` moves the limit (rows)."""
         if self.masked or self.use_rnn or os.environ.get('NJODE_PLAN_DEFER', '1') == '0':
             return False
-        return 0 < n_obs <= int(os.environ.get('NJODE_PLAN_DEFER_MAX', '32768'))
+        return 0 < n_obs <= int(os.environ.get('NJODE_PLAN_DEFER_MAX', '262144'))
 
     def prefetch_plan(self, times, time_ptr, X, obs_idx, delta_t, T, start_X, n_obs_ot,
                       M=None, need_hT=None, defer=None):

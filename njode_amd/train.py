@@ -211,7 +211,7 @@ def train(dataset_arrays, metadata, epochs=1, batch_size=100, learning_rate=1e-3
             # kernels queued ahead delay the step's own; B >= 4 096: the plan (~0.1 ms) hides
             # beside the ODE kernels (bench.py: 1.19 -> 1.14 ms at 20 000 paths).
             n_next = len(nxt[2]) if nxt is not None else 0
-            # (round 5: up to ~32 000 rows the plan rides inside this step's ODE-forward launch --
+            # (round 5: up to ~260 000 rows the plan rides inside this step's ODE-forward launch --
             # no helper stream, it pays at every size: NJODE.plan_defer_ok)
             if plan_ahead and fused and n_next >= max(plan_ahead_min, 1) and \
                     (n_next <= 512 or n_next >= 4096 or
