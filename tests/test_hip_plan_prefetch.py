@@ -130,3 +130,44 @@ def test_a_plan_is_only_taken_by_the_very_batch_it_was_made_for():
     m.prefetch_plan(*a, need_hT=False)
     m.prefetch_plan(*b, need_hT=False)
     assert float(m.loss_and_grad(*b)[1]) == l_b and len(m._plans) == 1
+
+
+def test_deferred_plan_flush_hosting_by_another_model_and_lifetime():
+    """NJODE_C_PLAN_DEFER (round 5): the plan of a prefetched batch is launched by the NEXT forward call
+    on the stream -- whoever makes it -- or by njode_plan_flush / the plan's destructor; in every case
+    the consuming step gives the bits of a step that planned in line."""
+    import gc
+    from njode_amd import _lib
+    cfg = demo_cfg(dropout=0.1, device_outputs=True)
+    torch.manual_seed(0)
+    m = models.NJODE(**cfg).cuda().train()
+    torch.manual_seed(1)
+    other = models.NJODE(**cfg).cuda().train()
+    a = _demo_args(400, seed=4)
+    b = _demo_args(900, seed=5)
+    assert m.plan_defer_ok(int(a[1][-1]))
+    l0, g0 = _step(m, a, {}, False)
+    L = _lib.lib()
+    assert L.njode_plan_flush() == 0
+    # 1. flushed by hand
+    m.prefetch_plan(*a, need_hT=False)
+    assert m._plans[0].done is None and m._plans[0].pending
+    assert L.njode_plan_flush() == 1 and L.njode_plan_flush() == 0
+    l1, g1 = _step(m, a, {}, False, left=0)
+    assert l1 == l0 and torch.equal(g1, g0)
+    # 2. hosted by another model's step on another batch
+    m.prefetch_plan(*a, need_hT=False)
+    other.loss_and_grad(*b)
+    assert L.njode_plan_flush() == 0          # (it rode in that call's ODE-forward launch)
+    l2, g2 = _step(m, a, {}, False, left=0)
+    assert l2 == l0 and torch.equal(g2, g0)
+    # 3. the consuming call itself finds it pending: launched in front of it
+    l3, g3 = _step(m, a, {}, True)
+    assert l3 == l0 and torch.equal(g3, g0)
+    # 4. a plan nobody launches dies with its model: its destructor launches it before the buffer goes
+    m.prefetch_plan(*a, need_hT=False)
+    del m
+    gc.collect()
+    assert L.njode_plan_flush() == 0
+    torch.cuda.synchronize()
+    assert float(other.loss_and_grad(*b)[1]) > 0
