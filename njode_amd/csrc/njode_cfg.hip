@@ -179,8 +179,9 @@ static void launch_mfma_fwd(const KArgs& a, bool split, hipStream_t st) {
         else if (a.plan_job) {
           // the next batch's plan rides in front of this launch's own blocks (njode_plan.h)
           const PlanJob job = *(const PlanJob*)a.plan_job;
-          if (a.enc_fused) k_ode_fwd_mixed_plan<CC, DROP, true><<<a.n_blocks_fwd + job.P, 256, 0, st>>>(a, job);
-          else k_ode_fwd_mixed_plan<CC, DROP, false><<<a.n_blocks_fwd + job.P, 256, 0, st>>>(a, job);
+          // (never with NJODE_ENC_FUSED: that variant is two registers over the three-waves-per-SIMD
+          // limit once it carries the plan; njode_api.hip launches the plan in front of such a call)
+          k_ode_fwd_mixed_plan<CC, DROP, false><<<a.n_blocks_fwd + job.P, 256, 0, st>>>(a, job);
         }
         else if (a.enc_fused) k_ode_fwd_mixed<CC, DROP, true><<<a.n_blocks_fwd, 256, 0, st>>>(a);
         else k_ode_fwd_mixed<CC, DROP, false><<<a.n_blocks_fwd, 256, 0, st>>>(a);

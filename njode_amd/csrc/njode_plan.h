@@ -359,7 +359,11 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
   __syncthreads();
   for (int b = gtid; b < B; b += gthreads) {
     int prev = -1, kprev = 0;
-    constexpr int CH = 32;                     // 32 independent loads in flight
+    // 32 independent loads in flight.  (NOT more: the hosting kernel's register count is the maximum over
+    // the plan's branch and the forward's -- with 64 here k_ode_fwd_mixed_plan took 256 VGPRs instead of
+    // 154, the FORWARD's blocks fell to one wave per SIMD and the step went from 0.86 to 1.07 ms.  After
+    // touching this file: tools/isa_dump.sh 0 and look at .vgpr_count of k_ode_fwd_mixed_plan, <= 168.)
+    constexpr int CH = 32;
     for (int i0 = 0; i0 < nt; i0 += CH) {
       int rr[CH];
 #pragma unroll

@@ -391,3 +391,27 @@ def test_sigterm_to_the_spawning_parent_takes_the_ranks_down():
             break
         time.sleep(0.1)
     assert not alive, alive
+
+
+def test_hosting_the_plan_does_not_cost_the_ode_forward_a_wave():
+    """njode_plan.h: k_ode_fwd_mixed_plan runs the next batch's plan in its first blocks; a kernel's
+    register count is the maximum over its branches, so plan code that needs more registers than the
+    forward silently takes a wave per SIMD from EVERY forward block (seen: 64 loads in flight in the
+    column walk -> 256 VGPRs, step 0.86 -> 1.07 ms).  The build records the compiler's per-kernel
+    resources (njode_amd/csrc/_obj/kernel_resources.json): same occupancy with and without the plan."""
+    import json
+    import os
+    import pytest
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'njode_amd', 'csrc',
+                        '_obj', 'kernel_resources.json')
+    if not os.path.exists(path):
+        pytest.skip('no build record (python -m njode_amd.build writes it)')
+    res = json.load(open(path))
+    def targs(name, kernel):      # the template arguments: up to the mangled parameter list
+        return name.split(kernel, 1)[1].split('EEEv', 1)[0]
+    plain = {targs(k, 'k_ode_fwd_mixed'): v for k, v in res.items() if 'k_ode_fwd_mixedI' in k}
+    hosted = {targs(k, 'k_ode_fwd_mixed_plan'): v for k, v in res.items() if 'k_ode_fwd_mixed_plan' in k}
+    assert hosted and 2 * len(hosted) == len(plain)      # (no hosting variant of the NJODE_ENC_FUSED form)
+    for key, h in hosted.items():
+        p = plain[key]
+        assert h['occupancy'] == p['occupancy'] and h['vgpr_spill'] == 0, (key, h, p)
