@@ -804,10 +804,17 @@ class NJODE(torch.nn.Module):
             # one queue: the job is only described now; the next forward call on this stream carries
             # it (or launches it in front of itself).  Its pinned schedule slot stays held until then.
             cur = torch.cuda.current_stream(dev)
+            older, older_plans = self._deferred_slots, self._deferred_plans
+            self._deferred_slots, self._deferred_plans = [slot_i], []
             self._ring.hold(slot_i)
-            self._deferred_slots.append(slot_i)
             rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs),
                                   flags | _lib.C_PLAN_DEFER, buf.data_ptr(), buf.numel(), cur.cuda_stream)
+            # (a job that was still pending -- two prefetches without a forward between them -- has
+            # just been launched on `cur` by the library: its schedule slot is free behind that)
+            for p in older:
+                self._ring.release_after(p, cur)
+            for pl in older_plans:
+                pl.pending = False
             _lib.check(rc)
             done = None
         else:

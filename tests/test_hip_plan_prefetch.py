@@ -164,6 +164,14 @@ def test_deferred_plan_flush_hosting_by_another_model_and_lifetime():
     # 3. the consuming call itself finds it pending: launched in front of it
     l3, g3 = _step(m, a, {}, True)
     assert l3 == l0 and torch.equal(g3, g0)
+    # 3b. more prefetches in a row than the pinned ring has slots: every older job is launched by the next
+    # njode_plan_f32 and its slot handed back; the newest four plans stay queued
+    for _ in range(40):
+        m.prefetch_plan(*a, need_hT=False)
+    assert len(m._plans) == 4 and len(m._deferred_slots) == 1
+    l4, g4 = _step(m, a, {}, False, left=3)
+    assert l4 == l0 and torch.equal(g4, g0)
+    m._plans.clear()
     # 4. a plan nobody launches dies with its model: its destructor launches it before the buffer goes
     m.prefetch_plan(*a, need_hT=False)
     del m
