@@ -32,6 +32,9 @@ struct SplitCfg { int on, ns[2], nw[2]; float r[2]; int queue[2]; };   // queue[
 
 struct PlanJob {
   int P;                        // plan blocks in front of the launch (0: none)
+  int first_stage;              // 0: everything; 2: the dense matrix, the row times and the cleared histogram
+                                // are already in place (k_row_time: a call that plans in line hands its
+                                // encoder rows to a helper stream as soon as the row times exist)
   int n, B, K, n_times;
   int cs_shift, cs_nwb;         // row blocks of the counting sort: 2^cs_shift rows each
   const int* sched_src;         // pinned host copy of the schedule (device-visible), or null: already in place
@@ -294,6 +297,14 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
   // (hosted by the ODE forward: its waves keep the SIMD's matrix / vector pipe ~90 % busy; the plan's
   // short dependent instruction chains go first whenever they are ready)
   __builtin_amdgcn_s_setprio(3);
+  if (j.first_stage >= 2) {
+    // (the two barriers this launch does not need still get their P arrivals: the host hands out a
+    // counter SET per launch and every counter of it moves on by P)
+    if (P > 1 && tid == 0) {
+      __hip_atomic_fetch_add(j.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(j.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
   // ---- stage 0: schedule into place (block 0, from the pinned host copy), dense = -1, histogram = 0
   if (pb == 0) {
     if (j.sched_src)
@@ -349,6 +360,7 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
     }
   }
   plan_sync(j.sync + 1, j.sync_base, P);
+  }
   stamp(1);
   // ---- stage 2: every path walks its column in time order: links, item lengths, sort keys, the
   // length histogram (per block in LDS, integer atomics: order-independent).  k_jump from LDS.
