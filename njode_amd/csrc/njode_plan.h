@@ -11,8 +11,10 @@
 // THE ODE FORWARD'S LAUNCH of the current step (k_ode_fwd_mixed, njode_mfma_split.h): same queue, no
 // events, no dispatches of its own, beside a kernel that is long enough to cover it.  The stages are
 // separated by grid barriers among the P plan blocks (all of them resident from the start: they hold the
-// lowest block indices, P <= PLAN_MAX_BLOCKS); P = 1 needs workgroup barriers only.  The same body
-// is also a kernel of its own (k_plan_grid, njode_api.hip) for calls that build their plan in line.
+// lowest block indices; P = rows / 4096 + 1 <= 64 when hosted, at most 256 = one per CU: njode_api.hip);
+// P = 1 needs workgroup barriers only.  The same body is also a kernel of its own (k_plan_grid,
+// njode_api.hip) for calls that build their plan in line -- whole for small plans, from its third stage
+// on (first_stage = 2) behind k_row_time for large ones.
 //
 // Same arrays, bit for bit, as the multi-launch plan: the order is a stable counting sort whatever
 // the row-block size, the layout's sums are integers (tests/test_hip_switches.py).
@@ -24,7 +26,6 @@ namespace njode {
 constexpr int PLAN_KEYS = 512;            // K + 1 must fit
 constexpr int PLAN_TIMES = 1500;          // n_times + 1 must fit (beside the histogram)
 constexpr int PLAN_THREADS = 256;
-constexpr int PLAN_MAX_BLOCKS = 64;
 constexpr int PLAN_LDS_INTS = 4 * PLAN_KEYS + 96;
 constexpr int PLAN_SCAN_CHUNKS = 32;      // row blocks per key held in registers: 64 x 32 = 2 048
 constexpr int SPLIT_KMAX = 4095;
