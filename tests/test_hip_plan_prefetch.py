@@ -137,7 +137,10 @@ def test_deferred_plan_flush_hosting_by_another_model_and_lifetime():
     on the stream -- whoever makes it -- or by njode_plan_flush / the plan's destructor; in every case
     the consuming step gives the bits of a step that planned in line."""
     import gc
+    import os
     from njode_amd import _lib
+    if os.environ.get('NJODE_PLAN_DEFER', '1') == '0' or os.environ.get('NJODE_PLAN_GRID', '1') == '0':
+        pytest.skip('the deferred plan is switched off in this environment')
     cfg = demo_cfg(dropout=0.1, device_outputs=True)
     torch.manual_seed(0)
     m = models.NJODE(**cfg).cuda().train()
