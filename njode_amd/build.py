@@ -5,8 +5,9 @@ The kernels keep each lane's activations in registers, so every model *shape*
 is a separate template instantiation.  ``CONFIGS`` is the table of compiled
 shapes; ``NJODE_EXTRA_CONFIGS`` (env, ``;``-separated
 ``d,H,d_out,n_hidden,width,act,masked,current_t,residual,use_rnn``) appends to it.
-Each shape is compiled as four translation units (segment forward, segment
-backward, lockstep forward, lockstep backward) so the build parallelises over the host cores.
+Each shape is compiled as six translation units (segment forward, segment
+backward, lockstep forward, lockstep backward, wave-per-path lockstep forward / sweep) so the
+build parallelises over the host cores.
 
 Usage:  python -m njode_amd.build [--force] [-j N]
 """
@@ -142,6 +143,7 @@ def build(force=False, jobs=None, verbose=True):
                     'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                     'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
                     'njode_mfma_lock4.h', 'njode_plan.h')] + [hdr]
+    chain_deps = kernel_deps + [os.path.join(CSRC, 'njode_chain.h'), os.path.join(CSRC, 'njode_dpp.h')]
     gen_deps = [os.path.join(CSRC, n) for n in
                 ('njode_gen.hip', 'njode_gen.h', 'njode_gen_seg.h', 'njode_gen_host.h', 'njode_device.h',
                  'njode_error.h')] + [hdr]
@@ -155,7 +157,7 @@ def build(force=False, jobs=None, verbose=True):
         hdr, hdr_prod]
     tasks = []   # (object, command, digest)
     for i, (d, h, do, nh, w, act, masked, curt, res, rnn) in enumerate(cfgs):
-        for part in range(4):
+        for part in range(6):
             obj = os.path.join(OBJ, 'cfg{}_{}.o'.format(i, part))
             defs = ['-DNJ_ID={}'.format(i), '-DNJ_PART={}'.format(part), '-DNJ_D={}'.format(d),
                     '-DNJ_H={}'.format(h), '-DNJ_DO={}'.format(do), '-DNJ_NH={}'.format(nh),
@@ -163,7 +165,7 @@ def build(force=False, jobs=None, verbose=True):
                     '-DNJ_MASKED={}'.format(masked), '-DNJ_CURT={}'.format(curt),
                     '-DNJ_RES={}'.format(res), '-DNJ_ACC_TANH={}'.format(masked), '-DNJ_RNN={}'.format(rnn)]
             cmd = common + defs + [os.path.join(CSRC, 'njode_cfg.hip'), '-o', obj]
-            tasks.append((obj, cmd, _digest(kernel_deps, ' '.join(cmd))))
+            tasks.append((obj, cmd, _digest(chain_deps if part >= 4 else kernel_deps, ' '.join(cmd))))
     api_obj = os.path.join(OBJ, 'api.o')
     cmd = common + [os.path.join(CSRC, 'njode_api.hip'), '-o', api_obj]
     tasks.append((api_obj, cmd, _digest(api_deps, ' '.join(cmd))))

@@ -1,12 +1,16 @@
 // njode_cfg.hip -- one model shape, compiled once per entry of the build table
 // (njode_amd/build.py) and per NJ_PART (0 segment forward + registration,
-// 1 segment backward, 2 lockstep forward, 3 lockstep backward) with
+// 1 segment backward, 2 lockstep forward, 3 lockstep backward, 4 / 5 the wave-per-path lockstep
+// forward / adjoint sweep of njode_chain.h) with
 //   -DNJ_ID=.. -DNJ_D=.. -DNJ_H=.. -DNJ_DO=.. -DNJ_NH=.. -DNJ_W=.. -DNJ_ACT=..
 //   -DNJ_MASKED=.. -DNJ_CURT=.. -DNJ_RES=.. -DNJ_PART=..
 #include <cstdlib>
 #include <cstring>
 
 #include "njode_host.h"
+#if NJ_PART >= 4
+#include "njode_chain.h"
+#endif
 
 #define NJ_CAT_(a, b) a##b
 #define NJ_CAT(a, b) NJ_CAT_(a, b)
@@ -34,6 +38,11 @@ constexpr bool HAS_SPLIT = HAS_MFMA && SplitOk<C>::value;
 // masked shapes: one tile over the four waves of a block (njode_mfma_lock4.h); NJODE_LOCK4=0
 // keeps the one-wave kernels (maintainer A/B)
 constexpr bool HAS_Q4 = HAS_MFMA_SWEEP && Q4Ok<C>::value;
+// ... or, for small batches, one wave per path (njode_chain.h; the choice is KArgs::chain, made by
+// njode_api.hip's make_layout)
+constexpr bool HAS_CHAIN = HAS_Q4 && ChainOk<C>::value;
+hipError_t NJ_CAT(njode_chain_forward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
+hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 static inline bool lock4_on() {
   static const bool on = [] {
     const char* e = getenv("NJODE_LOCK4");
@@ -328,6 +337,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       ACT_FLOATS,
       HAS_Q4 ? Q4_ACT_FLOATS : 0,
       HAS_MFMA_SWEEP ? 1 : 0,
+      HAS_CHAIN ? 1 : 0,
       HAS_SPLIT ? 1 : 0,
       HAS_MFMA ? 1 : 0};
   return &ops;
@@ -384,6 +394,12 @@ template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) 
   }
 }
 template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
+  if constexpr (HAS_CHAIN) {
+    if (a.chain && !a.want_path) {
+      (void)NJ_CAT(njode_chain_forward_, NJ_ID)(a, DROP, st);
+      return;
+    }
+  }
   if constexpr (HAS_Q4) {
     if (!a.want_path && lock4_on() && (!a.save_traj || a.lact)) {
       const int n_tiles = cdiv(a.B, a.q4_pt);
@@ -406,8 +422,9 @@ template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, int
   a.want_path = path ? 1 : 0;
   a.want_loss = loss ? 1 : 0;
   if (ode == ODE_MFMA && HAS_MFMA_LOCK) {
-    lock_pack_frags<C>(a, st);
-    ProfScope ps("k_paths_fwd_mfma", st);
+    // (the wave-per-path kernels read the flat parameter vector themselves)
+    if (!(HAS_CHAIN && a.chain && !a.want_path)) lock_pack_frags<C>(a, st);
+    ProfScope ps(HAS_CHAIN && a.chain && !a.want_path ? "k_paths_fwd_chain" : "k_paths_fwd_mfma", st);
     lock_launch_mfma<C, DROP>(a, st);
   } else {
     ProfScope ps("k_paths_fwd", st);
@@ -432,10 +449,17 @@ template <class CC, bool DROP> static void lock_bwd_mfma(const KArgs& a, hipStre
     k_pack_net<typename CC::Dec, DS><<<cdiv(DS::NALL * 64, 256), 256, 0, st>>>(a.P + CC::OFF_DEC,
                                                                              a.frag_dec);
     {
-      ProfScope ps("k_paths_bwd_adj_mfma", st);
+      const bool chain = HAS_CHAIN && a.chain;
+      ProfScope ps(chain ? "k_paths_bwd_adj_chain" : "k_paths_bwd_adj_mfma", st);
       bool q4 = false;
+      if constexpr (HAS_CHAIN) {
+        if (chain) {
+          (void)NJ_CAT(njode_chain_sweep_, NJ_ID)(a, DROP, st);
+          q4 = true;
+        }
+      }
       if constexpr (HAS_Q4) {
-        if (lock4_on() && a.lact) {   // (lact: the saving forward was k_paths_fwd_q4)
+        if (!q4 && lock4_on() && a.lact) {   // (lact: the saving forward was k_paths_fwd_q4)
           k_paths_bwd_adj_q4<CC, DROP><<<cdiv(a.B, a.q4_pt), 256, 0, st>>>(a);
           q4 = true;
         }
@@ -495,6 +519,48 @@ template <bool DROP> static hipError_t lock_bwd_t(const KArgs& a, int ode, hipSt
 }
 hipError_t NJ_CAT(njode_lock_backward_, NJ_ID)(const KArgs& a, bool drop, int ode, hipStream_t st) {
   return drop ? lock_bwd_t<true>(a, ode, st) : lock_bwd_t<false>(a, ode, st);
+}
+#endif
+
+#if NJ_PART >= 4
+// waves (= paths) per block: as few as still give every path a SIMD of its own
+static inline int chain_waves_per_block(int B) {
+  static const int env = getenv("NJODE_CHAIN_WPB") ? atoi(getenv("NJODE_CHAIN_WPB")) : 0;
+  if (env >= 1 && env <= CHAIN_MAX_WAVES) return env;
+  int w = 1;
+  while (w < CHAIN_MAX_WAVES && cdiv(B, w) > 256) w *= 2;
+  return w;
+}
+#endif
+#if NJ_PART == 4
+hipError_t NJ_CAT(njode_chain_forward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
+  if constexpr (HAS_CHAIN) {
+    const int wpb = chain_waves_per_block(a.B);
+    if (drop) {
+      const long long items = (long long)a.K * a.B + (long long)a.n_obs * 3 + a.B;
+      const int nb = (int)(items / 256 + 1 < 4096 ? items / 256 + 1 : 4096);
+      k_chain_bits<C><<<nb, 256, 0, st>>>(a);
+      k_paths_fwd_chain<C, true><<<cdiv(a.B, wpb), 64 * wpb, 0, st>>>(a);
+    } else {
+      k_paths_fwd_chain<C, false><<<cdiv(a.B, wpb), 64 * wpb, 0, st>>>(a);
+    }
+    return hipGetLastError();
+  } else {
+    return hipErrorNotSupported;
+  }
+}
+#endif
+
+#if NJ_PART == 5
+hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
+  if constexpr (HAS_CHAIN) {
+    const int wpb = chain_waves_per_block(a.B);
+    if (drop) k_paths_bwd_adj_chain<C, true><<<cdiv(a.B, wpb), 64 * wpb, 0, st>>>(a);
+    else k_paths_bwd_adj_chain<C, false><<<cdiv(a.B, wpb), 64 * wpb, 0, st>>>(a);
+    return hipGetLastError();
+  } else {
+    return hipErrorNotSupported;
+  }
 }
 #endif
 

@@ -149,12 +149,27 @@ struct KArgs {
   // the other blocks one wave per tile (njode_mfma_split.h); grid sizes
   int n_split_blocks, n_blocks_bwd, n_split_fwd, n_blocks_fwd;
   int q4_pt;       // masked lockstep kernels (njode_mfma_lock4.h): paths per 16-lane tile
+  // masked lockstep kernels in the latency regime (njode_chain.h): one wave per path; lact / jact /
+  // dbits / dbits_row then have that file's layouts
+  int chain;
   // segment plan, round 5 (NJODE_ENC_FUSED=1): the one-wave role of k_ode_fwd_mixed evaluates
   // encoder(X) of an item's START row itself (njode_ode2.h); k_encode_rows_items covers the rest
   int enc_fused;
   DropCtx dc;
   float keep;
 };
+
+// Shapes the wave-per-path lockstep kernels (njode_chain.h) are written for, and their records
+template <class C, bool TWO = (C::NH == 2)> struct ChainOk { static constexpr bool value = false; };
+template <class C> struct ChainOk<C, true> {
+  static constexpr bool value =
+      C::MASKED && !C::RNN && C::W <= 64 && C::H <= 64 && C::D <= 64 && C::DO <= 64 && C::D == C::DO &&
+      (C::ENC_CASE == 0 || (C::ENC_CASE == 1 && C::D == C::H)) &&
+      (C::DEC_CASE == 0 || (C::DEC_CASE == 1 && C::DO == C::H));
+};
+constexpr int CHAIN_MAX_WAVES = 8;              // waves (= paths) per block
+constexpr int CHAIN_ACT_FLOATS = 2 * 64;        // stored hidden activations per (path, Euler step): [layer][lane]
+constexpr int CHAIN_JACT_FLOATS = 3 * 2 * 64;   // ... per observation row: [evaluation][layer][lane]
 
 // ---- small per-lane helpers -------------------------------------------------------
 template <int N> NJ_DEV void load_vec(const float* p, float (&v)[N]) {

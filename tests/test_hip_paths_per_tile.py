@@ -51,11 +51,13 @@ def _run(tmp_path, tag, width, env_extra):
 
 @pytest.mark.parametrize('family,width,var', [('specialised', 50, 'NJODE_LOCK4_PT'), ('generic', 72, 'NJODE_GEN_PT')])
 def test_training_step_does_not_depend_on_the_paths_per_tile(tmp_path, family, width, var):
-    ref = _run(tmp_path, 'pt16', width, {var: '16'})
+    # (NJODE_CHAIN_MAX=0: the matrix-core tiles, not the wave-per-path kernels that a batch of this
+    # size runs by default since round 6 -- those are compared with the tiles below)
+    ref = _run(tmp_path, 'pt16', width, {var: '16', 'NJODE_CHAIN_MAX': '0'})
     n_h = 37 * 41
     assert np.isfinite(ref).all() and abs(ref[0]) > 0
     for pt in ('4', '1', '0'):                      # ('0': the library's own choice)
-        got = _run(tmp_path, 'pt' + pt, width, {var: pt})
+        got = _run(tmp_path, 'pt' + pt, width, {var: pt, 'NJODE_CHAIN_MAX': '0'})
         assert got[0] == pytest.approx(ref[0], rel=2e-5), (family, pt)
         np.testing.assert_allclose(got[1:1 + n_h], ref[1:1 + n_h], atol=2e-5, rtol=1e-4)
         assert rel_l2(got[1 + n_h:], ref[1 + n_h:]) < 1e-4, (family, pt)
@@ -64,9 +66,30 @@ def test_training_step_does_not_depend_on_the_paths_per_tile(tmp_path, family, w
 def test_keep_bits_drawn_ahead_are_the_bits_drawn_in_the_kernel(tmp_path):
     """specialised masked forward: k_q4_bits against q4_ode_keep / q4_row_keep -- the same masks,
     so the same loss, hT and gradient BIT FOR BIT (one path per tile in both runs)."""
-    a = _run(tmp_path, 'ahead', 50, {'NJODE_LOCK4_PT': '1', 'NJODE_DROP_BITS_AHEAD': '1'})
-    b = _run(tmp_path, 'inside', 50, {'NJODE_LOCK4_PT': '1', 'NJODE_DROP_BITS_AHEAD': '0'})
+    a = _run(tmp_path, 'ahead', 50, {'NJODE_LOCK4_PT': '1', 'NJODE_DROP_BITS_AHEAD': '1', 'NJODE_CHAIN_MAX': '0'})
+    b = _run(tmp_path, 'inside', 50, {'NJODE_LOCK4_PT': '1', 'NJODE_DROP_BITS_AHEAD': '0', 'NJODE_CHAIN_MAX': '0'})
     assert np.array_equal(a, b)
+
+
+def test_wave_per_path_kernels_draw_the_masks_of_the_matrix_core_tiles(tmp_path):
+    """round 6, njode_chain.h: one wave per path with a lane per unit against one 16-lane tile over four
+    waves (njode_mfma_lock4.h), dropout ON.  k_chain_bits re-assembles the lane-group streams into
+    64-bit lane masks, so both runs drop the SAME units: loss, hT and the gradient agree to fp32
+    summation order -- a wrong bit anywhere would show as a 1e-2 difference.  Blocks of one and of
+    four waves (NJODE_CHAIN_WPB) must give the same numbers bit for bit: the waves of a block share
+    nothing but read-only LDS tables."""
+    tiles = _run(tmp_path, 'tiles', 50, {'NJODE_CHAIN_MAX': '0'})
+    chain = _run(tmp_path, 'chain', 50, {})
+    n_h = 37 * 41
+    assert np.isfinite(chain).all() and abs(chain[0]) > 0
+    assert chain[0] == pytest.approx(tiles[0], rel=2e-5)
+    np.testing.assert_allclose(chain[1:1 + n_h], tiles[1:1 + n_h], atol=2e-5, rtol=1e-4)
+    assert rel_l2(chain[1 + n_h:], tiles[1 + n_h:]) < 1e-4
+    for wpb in ('1', '4', '8'):
+        got = _run(tmp_path, 'chain_wpb' + wpb, 50, {'NJODE_CHAIN_WPB': wpb})
+        assert np.array_equal(got[:1 + n_h], chain[:1 + n_h]), wpb
+        # (the gradient's slab reduction does not depend on the block shape of the sweep either)
+        assert np.array_equal(got, chain), wpb
 
 
 _SNIPPET_BS = r'''

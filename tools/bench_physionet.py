@@ -4,7 +4,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from njode_amd import _lib, models, synthetic_physionet  # noqa: E402
 NN = ((50, 'tanh'), (50, 'tanh'))
-for B in (50, 800):
+for B in [int(x) for x in os.environ.get('BATCHES', '50,800').split(',')]:
     cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
                use_rnn=False, bias=True, dropout_rate=float(os.environ.get('DROPOUT', '0.0')),
                options={'masked': True, 'device_outputs': True})
