@@ -238,6 +238,48 @@ def small_batch_ms(model, opt, dev, dt, T, sizes=(100, 200), steps=30, prefetch=
     return out
 
 
+def config5_ms(dev, dropout, sizes=(50, 800, 1000), steps=5):
+    """BASELINE config 5 (PhysioNet-shaped, physionet_train.py:93,326-353: d = H = 41, masked,
+    3 000 Euler steps): ms per training step (forward + exact backward + fused Adam, inputs resident)
+    at the reference's batch size (50), at 800 and at the per-GPU shard of the 8 000-patient data set
+    on 8 GPUs (1 000), each with its STRICT f32 fraction: SURVEY 8d's 8 750 MAC per Euler step and
+    path x 3 (forward + exact backward) against the 157.3 TF peak.  An extra outside `value`."""
+    from njode_amd import models, synthetic_physionet
+    out = {}
+    cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
+               use_rnn=False, bias=True, dropout_rate=dropout,
+               options={'masked': True, 'device_outputs': True})
+    for bsz in sizes:
+        b = synthetic_physionet.make_batch(batch_size=bsz, seed=0)
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sys.stderr):
+            m = models.NJODE(**cfg).to(dev).train()
+        opt = models.FusedAdam(m, lr=1e-3, weight_decay=0.0005)
+        args = (b['times'], b['time_ptr'], b['X'].to(dev), b['obs_idx'].to(dev, torch.int32), b['delta_t'],
+                b['T'], b['start_X'].to(dev), b['n_obs_ot'].to(dev, torch.int32))
+        M = b['M'].to(dev)
+
+        def one():
+            m.loss_and_grad(*args, M=M)
+            opt.step()
+
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        n_steps = int(round(float(b['T']) / float(b['delta_t'])))
+        flops = 2.0 * 8750 * 3 * n_steps * bsz
+        out[bsz] = {'ms': round(ms, 3), 'paths_per_s': round(bsz / (ms * 1e-3), 1), 'euler_steps': n_steps,
+                    'strict_tflops': round(flops / (ms * 1e-3) / 1e12, 3),
+                    'strict_frac': round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 5)}
+        del m, opt
+    return out
+
+
 def autograd_route_ms(dev, dt, T, step_args, dropout, steps):
     """The literal call sequence of the reference's training loop (train.py:492-523) on the same
     resident batch: optimizer.zero_grad(); hT, loss = model(...); loss.backward();
@@ -264,6 +306,56 @@ def autograd_route_ms(dev, dt, T, step_args, dropout, steps):
         one()
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / steps
+
+
+def comm_probe(model, dev, world, step_args, reps=50):
+    """What sets an N-GPU step beside the kernels, each measured ALONE (N > 1 only; extras outside
+    `value`): the step's one collective -- all-reduce (SUM) of the [P + 1] gradient bucket -- with
+    the ranks aligned by a barrier (`allreduce_alone_ms`: pure collective, no waiting for a slower
+    rank), the same collective on ONE float (`allreduce_4B_ms`: the latency floor of a one-shot
+    exchange; SURVEY section 5: 40 KB over xGMI is latency, not bandwidth), and the ranks' local
+    step without any collective (`local_compute_ms_by_rank`: the shard imbalance).  The in-loop
+    `allreduce_ms` of the headline contains both the collective and the wait for the slowest rank;
+    these three say which of the two sets the scaling curve."""
+    dist = torch.distributed
+    bucket = model.grad_bucket().detach().clone()
+    tiny = torch.zeros(1, device=dev)
+
+    def timed(t):
+        for _ in range(5):
+            dist.all_reduce(t)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(t)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ar_bucket, ar_tiny = timed(bucket), timed(tiny)
+    model._plans.clear()
+    for _ in range(3):
+        model.loss_and_grad(*step_args)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        model.loss_and_grad(*step_args)
+    torch.cuda.synchronize()
+    local = torch.tensor([1e3 * (time.perf_counter() - t0) / 10], device=dev, dtype=torch.float64)
+    allr = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(allr, local)
+    mx = torch.tensor([ar_bucket, ar_tiny], device=dev, dtype=torch.float64)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return {'bucket_bytes': int(bucket.numel() * 4), 'allreduce_alone_ms': round(float(mx[0]), 5),
+            'allreduce_4B_ms': round(float(mx[1]), 5),
+            'local_compute_ms_by_rank': [round(float(x), 4) for x in allr],
+            'note': 'local compute = plan in line + forward + backward of the rank\'s shard, no collective, '
+                    'no optimizer; allreduce_* = max over ranks of the mean of {} back-to-back '
+                    'collectives behind a barrier'.format(reps)}
 
 
 def strong_scaling_20k(model, opt, dev, world, rank, steps, warmup, prefetch):
@@ -430,6 +522,8 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-small-batch', action='store_true')
     ap.add_argument('--no-autograd-route', action='store_true')
+    ap.add_argument('--no-config5', action='store_true',
+                    help='skip the PhysioNet-shaped extras c5_b50_ms / c5_b800_ms / c5_b1000_ms')
     ap.add_argument('--no-strong-20k', action='store_true',
                     help='N > 1, weak scaling: skip the extra strong-scaling pass over the 20 000-path batch')
     ap.add_argument('--dump-params', default='',
@@ -569,6 +663,7 @@ def main():
     if args.dump_params and rank == 0:
         np.save(args.dump_params, flat.cpu().numpy())
 
+    comm = comm_probe(model, dev, world, step_args) if distributed else None
     strong20 = None
     if distributed and not strong and not args.no_strong_20k:
         strong20 = strong_scaling_20k(model, opt, dev, world, rank, args.steps, min(args.warmup, 10), prefetch)
@@ -600,6 +695,7 @@ def main():
             out['rccl_world'] = torch.distributed.get_world_size()
             out['collective_backend'] = backend + (' (RCCL)' if backend == 'nccl' else '')
             out['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 5)
+            out['comm'] = comm
             out['allreduce_floats'] = int(model.grad_bucket().numel())   # gradient + the loss slot
             out['ms_per_step_by_rank'] = [round(1e3 * x / args.steps, 4) for x in per_rank]
             if strong20 is not None:
@@ -682,6 +778,16 @@ def main():
             out['autograd_route_ms'] = round(autograd_route_ms(dev, dt, T, step_args, args.dropout,
                                                                args.steps), 4)
             out['autograd_route_paths_per_s'] = round(B / (out['autograd_route_ms'] * 1e-3), 1)
+        if world == 1 and not args.no_config5:
+            c5 = config5_ms(dev, args.dropout)
+            for bsz, v in c5.items():
+                out['c5_b{}_ms'.format(bsz)] = v['ms']
+            out['config5'] = {'workload': 'PhysioNet-shaped masked batch (synthetic_physionet.py: d = H = 41, '
+                                          '3 000 Euler steps, 30-100 observation times per path), training step '
+                                          '= forward + exact backward + fused Adam, dropout as the headline',
+                              'strict_flops_note': '2 x 8 750 MAC x 3 (fwd + bwd) x Euler steps x paths (SURVEY 8d)',
+                              'peak_tflops': FP32_MFMA_PEAK_TF,
+                              **{'b{}'.format(k): v for k, v in c5.items()}}
         if world == 1 and not args.no_cpu_baseline:
             with contextlib.redirect_stdout(sys.stderr):
                 out['cpu_baseline'] = cpu_baseline(dt, T)

@@ -10,10 +10,26 @@
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / STL types.
  *   - every pointer except `NjodeDims*`, `NjodeSchedule` host arrays and
- *     `size_t* out` is a DEVICE pointer; the caller owns every buffer.  The
- *     library allocates nothing persistent and keeps no global state except a
- *     thread-local error string.
- *   - all work is enqueued on the caller's `hipStream_t`; nothing synchronises.
+ *     `size_t* out` is a DEVICE pointer; the caller owns every data buffer
+ *     (parameters, batch, outputs, workspace, plan).
+ *   - state the library keeps (all of it; none holds caller data):
+ *       per thread   the error string of njode_last_error(); ONE pending plan job
+ *                    (njode_plan_f32 with NJODE_C_PLAN_DEFER: a description, launched
+ *                    by the thread's next njode_forward_f32 / njode_plan_f32 /
+ *                    njode_plan_flush call);
+ *       per process  two helper HIP streams and four events, created on first use,
+ *                    for calls that build their plan in line (pack + encoder rows and
+ *                    the hT tails run beside the plan); the kernel-timing records of
+ *                    njode_profile_enable; the switches of DESIGN.md section 4g, each
+ *                    read once from the environment;
+ *       per device   64 bytes + 16 KB of device memory, allocated on first use: one
+ *                    word that a grid barrier of the one-launch plan sets when it gives
+ *                    up waiting (njode_plan_barrier_failures) and the stage stamps of
+ *                    NJODE_PLAN_STAMPS=1.  The barrier COUNTERS of a plan are eight
+ *                    words of that plan's own buffer.
+ *   - all work is enqueued on the caller's `hipStream_t` (and, for in-line plans,
+ *     on the helper streams, ordered against it by events); nothing synchronises
+ *     except the functions that say so.
  *   - return 0 on success, an NJODE_E_* code otherwise (message via
  *     njode_last_error()).  No exceptions cross the ABI.
  *   - float data is fp32; indices are int32.
@@ -307,12 +323,21 @@ const char* njode_last_error(void);
  * Measurement aid (not part of the replaced reference surface): when enabled,
  * every hot-path kernel launch is bracketed by hipEvents recorded on the launch
  * stream.  njode_profile_read synchronises the device and writes one line per
- * kernel, "<name> <launches> <total_ms>\n", then clears the records.  This is the
- * library's only process-global state.  on = 1: every kernel (twelve events per training step,
+ * kernel, "<name> <launches> <total_ms>\n", then clears the records (process-global
+ * state: see "state the library keeps" at the top).  on = 1: every kernel (twelve events per training step,
  * ~3.5 % of a 1.1 ms step); on = 2: the ODE backward kernel only (two events).
  */
 int njode_profile_enable(int on);
 int njode_profile_read(char* out, size_t cap);
+
+/*
+ * 1 when a grid barrier of a one-launch plan (njode_plan_f32, or the plan an njode_forward_f32 call
+ * built in line) gave up waiting since the last call -- the plans built since then are invalid and
+ * must be rebuilt; njode_last_error() says so -- 0 otherwise, -1 on a HIP error.  The barrier's spin is
+ * bounded (seconds), so a lost block shows up here instead of as a hung device.  SYNCHRONISES the
+ * device: for tests and NJODE_VALIDATE-style checks, not for the hot loop.
+ */
+int njode_plan_barrier_failures(void);
 
 /* Build information: "gfx950;<list of compiled specialisations>". */
 const char* njode_build_info(void);

@@ -25,7 +25,7 @@ C_GEN_LOCKSTEP = 0x200      # shape-generic kernels: unmasked loss calls stay on
 C_PLAN_DEFER = 0x800        # njode_plan_f32: the plan rides in front of the next forward call's ODE-forward launch
 
 EXPORTS = ('njode_supported', 'njode_param_count', 'njode_workspace_bytes',
-           'njode_plan_bytes', 'njode_plan_f32', 'njode_plan_flush',
+           'njode_plan_bytes', 'njode_plan_f32', 'njode_plan_flush', 'njode_plan_barrier_failures',
            'njode_forward_f32', 'njode_backward_f32', 'njode_backward_loss_f32',
            'njode_adam_step_f32',
            'njode_last_error', 'njode_build_info', 'njode_profile_enable',
@@ -115,6 +115,8 @@ def lib():
     L.njode_plan_f32.restype = C.c_int
     L.njode_plan_flush.argtypes = []
     L.njode_plan_flush.restype = C.c_int
+    L.njode_plan_barrier_failures.argtypes = []
+    L.njode_plan_barrier_failures.restype = C.c_int
     L.njode_forward_f32.argtypes = [C.POINTER(NjodeDims), vp, C.POINTER(NjodeBatch),
                                     C.POINTER(NjodeSchedule), i32, f32, f32, u64,
                                     vp, vp, vp, vp, vp, sz, vp]

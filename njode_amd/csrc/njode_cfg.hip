@@ -10,6 +10,7 @@
 #include "njode_host.h"
 #if NJ_PART >= 4
 #include "njode_chain.h"
+#include "njode_chain_seg.h"
 #endif
 
 #define NJ_CAT_(a, b) a##b
@@ -43,6 +44,10 @@ constexpr bool HAS_Q4 = HAS_MFMA_SWEEP && Q4Ok<C>::value;
 constexpr bool HAS_CHAIN = HAS_Q4 && ChainOk<C>::value;
 hipError_t NJ_CAT(njode_chain_forward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
+// the segment plan's ODE kernels with one wave per item (njode_chain_seg.h; KArgs::seg_chain)
+constexpr bool HAS_SEG_CHAIN = HAS_SPLIT && HAS_MFMA_SWEEP && SegChainOk<C>::value;
+hipError_t NJ_CAT(njode_seg_chain_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, hipStream_t st);
+hipError_t NJ_CAT(njode_seg_chain_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 static inline bool lock4_on() {
   static const bool on = [] {
     const char* e = getenv("NJODE_LOCK4");
@@ -91,6 +96,12 @@ __global__ void k_pack_all_bits(KArgs a, int n_pack) {
     else if (idx < 2 * N + NE) pack_net_value<typename C::Enc, ES>(a.P + C::OFF_ENC, a.frag_enc, idx - 2 * N);
     else if (idx < 2 * N + NE + ND) pack_net_value<typename C::Dec, DS>(a.P + C::OFF_DEC, a.frag_dec, idx - 2 * N - NE);
   } else {
+    if constexpr (SegChainOk<C>::value) {
+      if (a.seg_chain) {   // (the wave-per-item forward's lane masks: njode_chain_seg.h)
+        seg_chain_bits_body<C>(a, (int)blockIdx.x - n_pack, (int)gridDim.x - n_pack);
+        return;
+      }
+    }
     if constexpr (HAS_SPLIT) {
       const int nb = (int)gridDim.x - n_pack;
       drop_bits_tile_steps<C>(a, ((int)blockIdx.x - n_pack) * 4 + (threadIdx.x >> 6), nb * 4);
@@ -111,7 +122,8 @@ template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st
       // one wave per 8 Euler steps of a four-wide tile; the number of such tiles is known on the
       // device only: enough waves for the small plans (every tile four-wide), a persistent
       // grid for the large ones
-      const long long work = (long long)cdiv(a.n_obs, 16) * cdiv(a.K > 0 ? a.K : 1, 8);
+      const long long work = a.seg_chain ? (long long)a.K * a.B / 64 + 1   // (256 (path, step) pairs per block)
+                                         : (long long)cdiv(a.n_obs, 16) * cdiv(a.K > 0 ? a.K : 1, 8);
       const int nb = (int)(work / 4 + 1 < 1024 ? work / 4 + 1 : 1024);
       k_pack_all_bits<CC, ES, DS><<<n_pack + nb, 256, 0, st>>>(a, n_pack);
     } else {
@@ -161,7 +173,8 @@ static void launch_mfma_rows_bwd(const KArgs& a, bool split, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     // (defer_loss == 2, NJODE_C_ROWS_IN_FWD: the forward call already ran this pass)
     if (a.defer_loss != 2) launch_jump_rows_bwd<CC, DROP>(a, st);
-    launch_ode_bwd_mfma<CC, DROP>(a, split, st);
+    if (HAS_SEG_CHAIN && a.seg_chain) (void)NJ_CAT(njode_seg_chain_backward_, NJ_ID)(a, DROP, st);
+    else launch_ode_bwd_mfma<CC, DROP>(a, split, st);
     {
       ProfScope ps("k_encode_rows_bwd_mfma", st);
       k_encode_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
@@ -234,8 +247,10 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
       // chain of its longest tile; in the mixed kernel of a large plan the four-wave blocks are
       // ~10 % of the work and the extra blocks of this launch cost more than they save:
       // 20 000 paths, k_pack_all 7.5 -> 12.3 us for ~1.5 us off k_ode_fwd_mixed)
-      const bool bits = DROP && HAS_SPLIT && a.ode_split && a.dbits && !side && !bits_off &&
-                        a.n_split_fwd == a.n_blocks_fwd;
+      // ... and the wave-per-item forward's lane masks (they need nothing of the plan: any stream)
+      const bool bits = a.seg_chain ? (DROP && a.dbits != nullptr)
+                                    : (DROP && HAS_SPLIT && a.ode_split && a.dbits && !side && !bits_off &&
+                                       a.n_split_fwd == a.n_blocks_fwd);
       ab.dbits_ready = bits ? 1 : 0;
       ProfScope ps("k_pack_all", s2);
       launch_pack_frags<C>(ab, s2, bits);
@@ -262,7 +277,8 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
     // the tails (hT: every path from its last observation to the end) need the encoder's outputs
     // and nothing else of this call: with helper streams they start TOGETHER with the items' ODE
     // forward, on a stream of their own, and share the chip with it
-    const bool tails_side = tails && side != nullptr;
+    const bool chain = HAS_SEG_CHAIN && ODE == ODE_MFMA && a.seg_chain != 0;   // (tails ride in its launch)
+    const bool tails_side = tails && side != nullptr && !chain;
     if (tails_side) {
       // the tails' stream waits for the encoder rows and for the plan's tail order: the latter is
       // on that stream itself (njode_api.hip, build_plan) or, failing that, on `st` -- then e0,
@@ -274,12 +290,16 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
         (void)hipStreamWaitEvent(side->st2, side->e0, 0);
       }
     }
-    {   // (the names are the launched kernels', as rocprofv3 lists them)
+    if (chain) {
+      ProfScope ps("k_seg_fwd_chain", st);
+      (void)NJ_CAT(njode_seg_chain_forward_, NJ_ID)(ab, DROP, tails, st);
+    } else {   // (the names are the launched kernels', as rocprofv3 lists them)
       ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_mixed" : "k_ode_fwd_mfma")
                                    : "k_ode_fwd_items", st);
       launch_ode_fwd<DROP, false, ODE>(ab, st);
     }
-    if (tails_side) {
+    if (chain) {
+    } else if (tails_side) {
       // (queued behind the forward's launch only so that the items' kernel is dispatched first)
       ProfScope ps(ODE == ODE_MFMA ? (HAS_SPLIT && a.ode_split ? "k_ode_fwd_split.tails" : "k_ode_fwd_mfma.tails")
                                    : "k_ode_fwd_items.tails", side->st2);
@@ -338,6 +358,7 @@ const CfgOps* NJ_CAT(njode_cfg_ops_, NJ_ID)() {
       HAS_Q4 ? Q4_ACT_FLOATS : 0,
       HAS_MFMA_SWEEP ? 1 : 0,
       HAS_CHAIN ? 1 : 0,
+      HAS_SEG_CHAIN ? 1 : 0,
       HAS_SPLIT ? 1 : 0,
       HAS_MFMA ? 1 : 0};
   return &ops;
@@ -551,7 +572,48 @@ hipError_t NJ_CAT(njode_chain_forward_, NJ_ID)(const KArgs& a, bool drop, hipStr
 }
 #endif
 
+#if NJ_PART == 4
+hipError_t NJ_CAT(njode_seg_chain_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, hipStream_t st) {
+  if constexpr (HAS_SEG_CHAIN) {
+    const int nb = cdiv(a.n_obs + a.B, 4);
+    if (drop && !a.dbits_ready) {
+      const long long items = (long long)a.K * a.B;
+      k_seg_chain_bits<C><<<(int)(items / 256 + 1 < 2048 ? items / 256 + 1 : 2048), 256, 0, st>>>(a);
+    }
+    if (a.plan_job) {
+      // the next batch's plan rides in front of this launch's own blocks (njode_plan.h)
+      const PlanJob job = *(const PlanJob*)a.plan_job;
+      if (drop) k_seg_fwd_chain_plan<C, true><<<nb + job.P, 256, 0, st>>>(a, tails ? 1 : 0, job);
+      else k_seg_fwd_chain_plan<C, false><<<nb + job.P, 256, 0, st>>>(a, tails ? 1 : 0, job);
+    } else {
+      if (drop) k_seg_fwd_chain<C, true><<<nb, 256, 0, st>>>(a, tails ? 1 : 0);
+      else k_seg_fwd_chain<C, false><<<nb, 256, 0, st>>>(a, tails ? 1 : 0);
+    }
+    return hipGetLastError();
+  } else {
+    return hipErrorNotSupported;
+  }
+}
+#endif
+
 #if NJ_PART == 5
+hipError_t NJ_CAT(njode_seg_chain_backward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
+  if constexpr (HAS_SEG_CHAIN) {
+    {
+      ProfScope ps("k_seg_bwd_chain", st);
+      if (drop) k_seg_bwd_chain<C, true><<<cdiv(a.n_obs, 4), 256, 0, st>>>(a);
+      else k_seg_bwd_chain<C, false><<<cdiv(a.n_obs, 4), 256, 0, st>>>(a);
+    }
+    {   // d loss / d ODE parameters from the stored adjoints: the lockstep plan's pair kernel
+      ProfScope ps("k_ode_dw_pairs_mfma", st);
+      if (drop) k_ode_dw_pairs_mfma<C, true><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
+      else k_ode_dw_pairs_mfma<C, false><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
+    }
+    return hipGetLastError();
+  } else {
+    return hipErrorNotSupported;
+  }
+}
 hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
   if constexpr (HAS_CHAIN) {
     const int wpb = chain_waves_per_block(a.B);

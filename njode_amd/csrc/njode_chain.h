@@ -38,30 +38,7 @@ namespace njode {
 
 constexpr int chain_q(int n) { return (n + 3) / 4; }
 
-// keep masks drawn ahead: [(b K + k) 2 + layer] for the Euler steps (path-major: four consecutive steps
-// of a path share a 64-byte line of the scalar cache), then per observation row
-// [(row 3 + evaluation) 2 + layer] (evaluation: 0 readout before, 1 encoder, 2 readout after), then
-// per path [(3 n_obs + b) 2 + layer] for the start encoder
-NJ_DEV size_t chain_step_bits(int k, int K, int b) { return ((size_t)b * K + k) * 2; }
-NJ_DEV size_t chain_row_bits(int row, int e) { return ((size_t)row * 3 + e) * 2; }
-
-// The lane-group streams of the matrix-core kernels (njode_mfma.h: unit 4 q + g is bit q of the
-// stream of lane group g) as 64-bit LANE masks of the DPP layout (njode_dpp.h: lane 16 g + q holds
-// unit 4 q + g): bit l = keep decision of the unit lane l holds -- the four streams' words side by side.
-template <int NQ>
-NJ_DEV void chain_masks(const DropCtx& dc, unsigned long long gid, uint32_t tkey, uint32_t net, uint64_t& m1,
-                        uint64_t& m2) {
-  static_assert(NQ <= 16, "16 units per lane group");
-  m1 = m2 = 0;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    uint32_t st = drop_state(dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1), tkey, net);
-    const uint32_t k1 = keep_bits<NQ>(st, dc.thr16);
-    const uint32_t k2 = keep_bits<NQ>(st, dc.thr16);
-    m1 |= (uint64_t)k1 << (16 * g);
-    m2 |= (uint64_t)k2 << (16 * g);
-  }
-}
+// (chain_step_bits / chain_row_bits / chain_masks: njode_mfma.h, beside the streams they re-assemble)
 
 template <class C> __global__ void __launch_bounds__(256) k_chain_bits(KArgs a) {
   uint64_t* sb = (uint64_t*)a.dbits;

@@ -111,4 +111,51 @@ template <int K> NJ_DEV float dpp_dot(float init, const float (&R)[4], const flo
   return K > 16 ? acc0 + acc1 : acc0;
 }
 
+// ---- one register, no replication -----------------------------------------------------------------
+// acc + sum_{n < K} w[n] * v[lane n of my row of 16]: the vector v is either the SAME in every row (a
+// small vector kept row-replicated: unit n in lane n of each row -- the H <= 16 state of the demo
+// models) or the row's own slice of a unit-layout vector (a K-split: row g sums the units = g mod 4,
+// dpp_rows_sum() adds the four partial sums).
+#define NJ_DPP_R(w, n) "v_fmac_f32_dpp %0, %1, %" #w " row_newbcast:%" #n " row_mask:0xf bank_mask:0xf\n\t"
+template <int N0, int CNT> NJ_DEV void dpp_row_block(float& acc, float v, const float* w) {
+  static_assert(CNT >= 1 && CNT <= 8 && N0 + CNT <= 16, "block of one to eight lanes");
+  if constexpr (CNT == 8)
+    asm(NJ_DPP_R(2, 10) NJ_DPP_R(3, 11) NJ_DPP_R(4, 12) NJ_DPP_R(5, 13) NJ_DPP_R(6, 14) NJ_DPP_R(7, 15) NJ_DPP_R(8, 16) NJ_DPP_R(9, 17)
+        : "+v"(acc)
+        : "v"(v), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "n"(N0),
+          "n"(N0 + 1), "n"(N0 + 2), "n"(N0 + 3), "n"(N0 + 4), "n"(N0 + 5), "n"(N0 + 6), "n"(N0 + 7));
+  else if constexpr (CNT >= 4) {
+    asm(NJ_DPP_R(2, 6) NJ_DPP_R(3, 7) NJ_DPP_R(4, 8) NJ_DPP_R(5, 9)
+        : "+v"(acc)
+        : "v"(v), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "n"(N0), "n"(N0 + 1), "n"(N0 + 2), "n"(N0 + 3));
+    if constexpr (CNT > 4) dpp_row_block<N0 + 4, CNT - 4>(acc, v, w + 4);
+  } else if constexpr (CNT == 3)
+    asm(NJ_DPP_R(2, 5) NJ_DPP_R(3, 6) NJ_DPP_R(4, 7)
+        : "+v"(acc) : "v"(v), "v"(w[0]), "v"(w[1]), "v"(w[2]), "n"(N0), "n"(N0 + 1), "n"(N0 + 2));
+  else if constexpr (CNT == 2)
+    asm(NJ_DPP_R(2, 4) NJ_DPP_R(3, 5) : "+v"(acc) : "v"(v), "v"(w[0]), "v"(w[1]), "n"(N0), "n"(N0 + 1));
+  else
+    asm(NJ_DPP_R(2, 3) : "+v"(acc) : "v"(v), "v"(w[0]), "n"(N0));
+}
+#undef NJ_DPP_R
+// (v must not have been written by the two preceding VALU instructions: dpp_settle)
+NJ_DEV void dpp_settle(float& v) { asm volatile("s_nop 1" : "+v"(v)); }
+template <int K> NJ_DEV float dpp_row_dot(float init, float v, const float (&w)[K]) {
+  static_assert(K >= 1 && K <= 16, "one row of 16 lanes");
+  float acc = init;
+  dpp_row_block<0, (K > 8 ? 8 : K)>(acc, v, w);
+  if constexpr (K > 8) dpp_row_block<8, K - 8>(acc, v, w + 8);
+  return acc;
+}
+// sum of a value over the four rows (lanes c, 16 + c, 32 + c, 48 + c), the same in all four:
+// (r0 + r2) + (r1 + r3), a fixed order
+NJ_DEV float dpp_rows_sum(float v) {
+  const unsigned a = __float_as_uint(v);
+  const dpp_u32x2 s = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // [r0 r1 r0 r1], [r2 r3 r2 r3]
+  const float t = __uint_as_float(s[0]) + __uint_as_float(s[1]);               // [r0+r2, r1+r3, r0+r2, r1+r3]
+  const unsigned b = __float_as_uint(t);
+  const dpp_u32x2 p = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // [t0 t0 t0 t0], [t1 t1 t1 t1]
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+
 }  // namespace njode

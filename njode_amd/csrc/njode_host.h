@@ -39,6 +39,7 @@ struct CfgOps {
   int lock_act_floats;             // lockstep plan (masked shapes): ... per tile of 16 paths and step
   int lock_sweep_mfma;  // the lockstep backward has a matrix-core adjoint sweep
   int lock_chain;       // ... and the lockstep plan has the wave-per-path kernels (njode_chain.h)
+  int seg_chain;        // the segment plan has the wave-per-item ODE kernels (njode_chain_seg.h)
   int ode_split;        // ODE_MFMA runs the mixed ODE kernels (njode_mfma_split.h)
   int seg_mfma;         // the segment plan has matrix-core kernels for this shape
 };

@@ -152,6 +152,9 @@ struct KArgs {
   // masked lockstep kernels in the latency regime (njode_chain.h): one wave per path; lact / jact /
   // dbits / dbits_row then have that file's layouts
   int chain;
+  // segment plan in the latency regime (njode_chain_seg.h): one wave per item; the ODE weight
+  // gradients then come from the lockstep plan's (step, path) pair kernel
+  int seg_chain;
   // segment plan, round 5 (NJODE_ENC_FUSED=1): the one-wave role of k_ode_fwd_mixed evaluates
   // encoder(X) of an item's START row itself (njode_ode2.h); k_encode_rows_items covers the rest
   int enc_fused;
@@ -166,6 +169,10 @@ template <class C> struct ChainOk<C, true> {
       C::MASKED && !C::RNN && C::W <= 64 && C::H <= 64 && C::D <= 64 && C::DO <= 64 && C::D == C::DO &&
       (C::ENC_CASE == 0 || (C::ENC_CASE == 1 && C::D == C::H)) &&
       (C::DEC_CASE == 0 || (C::DEC_CASE == 1 && C::DO == C::H));
+};
+template <class C, bool TWO = (C::NH == 2)> struct SegChainOk { static constexpr bool value = false; };
+template <class C> struct SegChainOk<C, true> {
+  static constexpr bool value = !C::MASKED && !C::RNN && C::W <= 64 && C::W > 16 && C::H <= 16 && C::D <= 8;
 };
 constexpr int CHAIN_MAX_WAVES = 8;              // waves (= paths) per block
 constexpr int CHAIN_ACT_FLOATS = 2 * 64;        // stored hidden activations per (path, Euler step): [layer][lane]

@@ -167,6 +167,47 @@ template <int NQ> NJ_DEV uint32_t keep_bits(uint32_t& s, uint32_t thr16) {
   return m;
 }
 
+// ---- the same streams as 64-bit LANE masks: the wave-per-path / wave-per-item kernels (njode_chain.h,
+// njode_chain_seg.h) ----
+// keep masks drawn ahead: [(b K + k) 2 + layer] for the Euler steps (path-major: four consecutive steps
+// of a path share a 64-byte line of the scalar cache), then per observation row
+// [(row 3 + evaluation) 2 + layer] (evaluation: 0 readout before, 1 encoder, 2 readout after), then
+// per path [(3 n_obs + b) 2 + layer] for the start encoder
+NJ_DEV size_t chain_step_bits(int k, int K, int b) { return ((size_t)b * K + k) * 2; }
+NJ_DEV size_t chain_row_bits(int row, int e) { return ((size_t)row * 3 + e) * 2; }
+
+// The lane-group streams of the matrix-core kernels (njode_mfma.h: unit 4 q + g is bit q of the
+// stream of lane group g) as 64-bit LANE masks of the DPP layout (njode_dpp.h: lane 16 g + q holds
+// unit 4 q + g): bit l = keep decision of the unit lane l holds -- the four streams' words side by side.
+template <int NQ>
+NJ_DEV void chain_masks(const DropCtx& dc, unsigned long long gid, uint32_t tkey, uint32_t net, uint64_t& m1,
+                        uint64_t& m2) {
+  static_assert(NQ <= 16, "16 units per lane group");
+  m1 = m2 = 0;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    uint32_t st = drop_state(dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1), tkey, net);
+    const uint32_t k1 = keep_bits<NQ>(st, dc.thr16);
+    const uint32_t k2 = keep_bits<NQ>(st, dc.thr16);
+    m1 |= (uint64_t)k1 << (16 * g);
+    m2 |= (uint64_t)k2 << (16 * g);
+  }
+}
+
+// keep masks of the ODE network for every (path, Euler step), drawn ahead of the wave-per-item forward
+// (worker of n_workers, 256 threads each)
+template <class C> NJ_DEV void seg_chain_bits_body(const KArgs& a, int worker, int n_workers) {
+  uint64_t* sb = (uint64_t*)a.dbits;
+  const long long n_ode = (long long)a.K * a.B;
+  for (long long i = (long long)worker * 256 + threadIdx.x; i < n_ode; i += (long long)n_workers * 256) {
+    const int b = (int)(i / a.K), k = (int)(i % a.K);
+    uint64_t m1, m2;
+    chain_masks<MF<C>::Q1>(a.dc, a.gid0 + b, (uint32_t)k, NET_ODE, m1, m2);
+    sb[i * 2] = m1;
+    sb[i * 2 + 1] = m2;
+  }
+}
+
 // hidden activation from accumulator tiles: a[q] = act(acc[q / 4][q % 4]) (+dropout),
 // then the bias unit (unit W) is set to 1
 template <int MT1, int Q1, int W, int ACT, bool DROP>

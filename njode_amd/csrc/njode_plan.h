@@ -36,6 +36,8 @@ struct PlanJob {
   int first_stage;              // 0: everything; 2: the dense matrix, the row times and the cleared histogram
                                 // are already in place (k_row_time: a call that plans in line hands its
                                 // encoder rows to a helper stream as soon as the row times exist)
+  int last_stage;               // 5: everything; 2: stop behind the links (the consumer runs one wave per
+                                // item, njode_chain_seg.h: it needs neither the order by length nor the layout)
   int n, B, K, n_times;
   int cs_shift, cs_nwb;         // row blocks of the counting sort: 2^cs_shift rows each
   const int* sched_src;         // pinned host copy of the schedule (device-visible), or null: already in place
@@ -58,8 +60,9 @@ struct PlanJob {
   int* order;
   long long* base_s;
   long long* base16_s;
-  unsigned* sync;               // [8] grid-barrier counters of the library's pool: they only ever count up,
-  unsigned sync_base;           // ... every launch on a set starts at the value the host tracks for it
+  unsigned* sync;               // [8] grid-barrier counters OF THIS PLAN (in its own buffer, zeroed on the launch's
+  unsigned sync_base;           // stream right before it: no two launches ever share a counter); base = 0
+  unsigned* fail;               // device word of the library: set when a barrier gave up waiting (plan_sync)
   unsigned long long* stamps;   // maintainer aid (NJODE_PLAN_STAMPS=1): [block][8] wall clock at the stage ends
   SplitCfg sc;
 };
@@ -82,14 +85,31 @@ template <bool COH, class T> __device__ __forceinline__ void pst(T* p, T v) {
 // Barrier among the P plan blocks: every wave waits for its own stores (write-through: acknowledged at
 // the coherence point), the workgroup meets, thread 0 counts the block in and waits for the others.
 // No cache-wide operation.
-__device__ inline void plan_sync(unsigned* ctr, unsigned base, int P) {
+//
+// Ordering: the handed-over data is written with sc1 stores, and what orders them in front
+// of the arrival is the s_waitcnt below -- inline assembly with a memory clobber, so the compiler can
+// move none of those stores (nor the histogram's global atomics) behind it; the same on the reader's
+// side behind the spin.  Visibility itself is MI355X_MICROARCH.md's measured sc1 / drained-counter form.
+//
+// The spin is BOUNDED: a barrier that is not complete after ~2^22 polls (seconds; a
+// healthy one takes microseconds) sets *fail and lets the launch run to its end -- on garbage, which the
+// host reports (njode_plan_barrier_failures(), checked by the tests) instead of a hung device.
+constexpr int PLAN_SPIN_MAX = 1 << 22;
+__device__ inline void plan_sync(unsigned* ctr, unsigned base, int P, unsigned* fail) {
   if (P > 1) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
       __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base) < P)
+      int spins = 0;
+      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base) < P) {
+        if (++spins > PLAN_SPIN_MAX) {
+          if (fail) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
         __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
   } else {
@@ -326,7 +346,7 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
       for (size_t i = (c4 << 2) + gtid; i < cells; i += gthreads) j.dense[i] = -1;
     }
   }
-  plan_sync(j.sync + 0, j.sync_base, P);
+  plan_sync(j.sync + 0, j.sync_base, P, j.fail);
   stamp(0);
   // ---- stage 1: time slice of every row (binary search over the CSR offsets, held in LDS), scatter
   // into the dense [time slice][path] matrix
@@ -360,7 +380,7 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
       }
     }
   }
-  plan_sync(j.sync + 1, j.sync_base, P);
+  plan_sync(j.sync + 1, j.sync_base, P, j.fail);
   }
   stamp(1);
   // ---- stage 2: every path walks its column in time order: links, item lengths, sort keys, the
@@ -403,8 +423,19 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
   __syncthreads();
   for (int s = tid; s < nkeys; s += NT)
     if (hist[s]) atomicAdd(&j.len_hist[s], hist[s]);
-  plan_sync(j.sync + 2, j.sync_base, P);
+  plan_sync(j.sync + 2, j.sync_base, P, j.fail);
   stamp(2);
+  if (j.last_stage <= 2) {
+    // (the two barriers this launch does not reach still get their P arrivals: see first_stage above)
+    if (P > 1 && tid == 0) {
+      __hip_atomic_fetch_add(j.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(j.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    stamp(3);
+    stamp(4);
+    stamp(5);
+    return;
+  }
   // ---- stage 3: counting sort, count: one wave per row block counts its rows per key in counters of
   // its own (integer LDS atomics) -> table[key][row block].  The LAST block derives the trajectory
   // layout instead (P == 1: the only block, after its share): it only needs the histogram.
@@ -441,7 +472,7 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
       return;
     }
   }
-  plan_sync(j.sync + 3, j.sync_base, P);
+  plan_sync(j.sync + 3, j.sync_base, P, j.fail);
   stamp(3);
   // ---- stage 4: scan: base of every key (exclusive scan of the histogram by descending length, in
   // LDS) + exclusive scan of the key's row over the row blocks -- a thread per key while a row is short
@@ -508,7 +539,7 @@ __device__ inline void plan_grid_stages(const PlanJob& j, int pb, int* lds) {
       }
     }
   }
-  plan_sync(j.sync + 4, j.sync_base, P);
+  plan_sync(j.sync + 4, j.sync_base, P, j.fail);
   stamp(4);
   // ---- stage 5: scatter: one wave per row block ranks its rows in row order (equal keys keep their
   // row order: nothing depends on timing)

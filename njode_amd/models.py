@@ -205,7 +205,7 @@ class _Plan:
     queued) and the version counter ``obs_idx`` had: a call only takes a plan of the very same,
     unmodified objects."""
     __slots__ = ('buf', 'done', 'flags', 'sizes', 'keep', 'pool', 'obs_idx', 'time_ptr',
-                 'obs_version', 'taken', 'pending')
+                 'obs_version', 'taken', 'pending', 'stream')
 
     def __del__(self):
         # a deferred plan nobody has launched yet must not outlive its buffer
@@ -624,8 +624,19 @@ class NJODE(torch.nn.Module):
         if plan is not None:
             cb.plan = plan.buf.data_ptr()
             flags |= _lib.C_PLAN_READY | (plan.flags & _lib.C_NEED_HT)
-            if plan.done is not None:    # (a deferred plan is on this very stream: stream order)
-                (stream if stream is not None else torch.cuda.current_stream(dev)).wait_event(plan.done)
+            use = stream if stream is not None else torch.cuda.current_stream(dev)
+            if plan.done is not None:
+                use.wait_event(plan.done)
+            elif plan.stream is not None and plan.stream.cuda_stream != use.cuda_stream:
+                # A deferred plan is ordered by its stream alone -- the one prefetch_plan saw.  A call
+                # that consumes it on ANOTHER stream (loss_and_grad(stream=...), a torch.cuda.stream
+                # context entered only around the step) would read a plan that may still be half
+                # built: launch the job if it is still pending (the library runs it on its own
+                # stream) and wait for that stream here.
+                L.njode_plan_flush()
+                ev = torch.cuda.Event()
+                ev.record(plan.stream)
+                use.wait_event(ev)
             keep.append(plan)
         need = ctypes.c_size_t(0)
         _lib.check(L.njode_workspace_bytes(ctypes.byref(dims), B, n_obs, nt, K, flags,
@@ -662,8 +673,12 @@ class NJODE(torch.nn.Module):
         """After an ``njode_forward_f32`` call: its pinned schedule slot is free once ``stream`` has
         passed it -- and so are the slots of deferred plans, which that call hosted or launched."""
         self._ring.release_after(slot_i, stream)
+        ds = getattr(self, '_deferred_stream', None)
         for p in self._deferred_slots:
-            self._ring.release_with(p, slot_i)
+            if ds is not None and ds.cuda_stream != stream.cuda_stream:
+                self._ring.release_after(p, ds)     # (the job ran on the stream it was described on)
+            else:
+                self._ring.release_with(p, slot_i)
         del self._deferred_slots[:]
         for pl in self._deferred_plans:
             pl.pending = False
@@ -806,6 +821,7 @@ class NJODE(torch.nn.Module):
             cur = torch.cuda.current_stream(dev)
             older, older_plans = self._deferred_slots, self._deferred_plans
             self._deferred_slots, self._deferred_plans = [slot_i], []
+            self._deferred_stream = cur
             self._ring.hold(slot_i)
             rc = L.njode_plan_f32(ctypes.byref(dims), ctypes.byref(cb), ctypes.byref(cs),
                                   flags | _lib.C_PLAN_DEFER, buf.data_ptr(), buf.numel(), cur.cuda_stream)
@@ -836,6 +852,7 @@ class NJODE(torch.nn.Module):
         plan.obs_idx, plan.time_ptr, plan.taken = obs_idx, time_ptr, False
         plan.obs_version = getattr(obs_idx, '_version', 0)
         plan.pending = bool(defer)
+        plan.stream = cur if defer else None
         if defer:
             self._deferred_plans.append(plan)
         self._plans.append(plan)

@@ -350,3 +350,41 @@ def test_c_abi_error_codes():
                              call.ws.data_ptr(), 1024, None)
     assert rc == _lib.E_WORKSPACE and b'workspace too small' in L.njode_last_error()
     m._release_ws(call)
+
+
+def test_the_bench_size_step_meets_the_oracle_directly():
+    """the regime bench.py times -- 20 000 seed-0 Black-Scholes paths (12 467
+    tiles, 3 - 4 static rounds per wave, the 1 024-row slab reduction), the FUSED step, its plan built
+    by the first blocks of the PREVIOUS step's ODE-forward launch (prefetch_plan's deferral) -- against
+    the CPU oracle's loss and autograd gradient on the same batch (dropout 0; ~7 s of CPU).  Until
+    round 6 this size was only reached through a chain of self-consistency tests."""
+    torch.manual_seed(0)
+    cfg = demo_cfg()
+    b, meta = bs_batch(20000, seed=0)
+    m = hip_model(cfg).train()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    (_, l_o), params = oracle_forward(cfg, sd, b, meta['dt'], meta['maturity'], grads=True)
+    l_o.backward()
+    flat_ref = np.concatenate([params[k].grad.numpy().reshape(-1) for k in sd])
+    d = to_dev(b)
+    obs_idx = d['obs_idx'].cuda().int()
+    args = (d['times'], d['time_ptr'], d['X'], obs_idx, meta['dt'], meta['maturity'], d['start_X'],
+            d['n_obs_ot'])
+    deferred = m.plan_defer_ok(int(np.asarray(d['time_ptr'])[-1]))
+    m.prefetch_plan(*args, need_hT=False)       # the plan of step 0
+    for step in range(3):
+        m.prefetch_plan(*args, need_hT=False)   # the plan of step + 1: rides in THIS step's ODE forward
+        if deferred:
+            assert m._plans[-1].done is None    # (deferred: no helper stream, no event)
+        _, loss = m.loss_and_grad(*args)        # consumes the oldest queued plan: the one built a step ago
+        assert len(m._plans) == 1
+    m._plans.clear()
+    got = m.flat_grad().cpu().numpy()
+    assert float(loss) == pytest.approx(float(l_o), rel=LOSS_RTOL)
+    assert rel_l2(got, flat_ref) < GRAD_REL_L2, rel_l2(got, flat_ref)
+    # per tensor as well: no network hides behind the flat norm
+    off = 0
+    for k in sd:
+        n = params[k].numel()
+        assert rel_l2(got[off:off + n], flat_ref[off:off + n]) < GRAD_REL_L2, k
+        off += n

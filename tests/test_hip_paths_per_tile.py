@@ -114,7 +114,9 @@ def test_segment_plan_keep_bits_ahead_are_the_bits_of_the_stream(tmp_path):
     res = {}
     for tag, val in (('ahead', '1'), ('inside', '0')):
         out = str(tmp_path / (tag + '_bs.npy'))
-        env = dict(os.environ, NJODE_DROP_BITS_AHEAD=val)
+        # (NJODE_SEG_CHAIN_MAX=0: the four-wave tiles this test is about, not the wave-per-item
+        # kernels a batch of this size runs by default since round 6)
+        env = dict(os.environ, NJODE_DROP_BITS_AHEAD=val, NJODE_SEG_CHAIN_MAX='0')
         p = subprocess.run([sys.executable, '-c', _SNIPPET_BS.format(tests=TESTS, repo=REPO, out=out)],
                            env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                            timeout=600)
@@ -122,3 +124,54 @@ def test_segment_plan_keep_bits_ahead_are_the_bits_of_the_stream(tmp_path):
         res[tag] = np.load(out)
     assert np.isfinite(res['ahead']).all() and abs(res['ahead'][0]) > 0
     assert np.array_equal(res['ahead'], res['inside'])
+
+
+_SNIPPET_SEG = r'''
+import sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {repo!r})
+import numpy as np, torch
+from hip_util import bs_batch, demo_cfg, hip_model
+b, meta = bs_batch({B}, seed=11)
+torch.manual_seed(0)
+m = hip_model(demo_cfg(dropout=0.1)).train()
+m._step_counter = 3
+args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'],
+        meta['maturity'], b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+_, loss = m.loss_and_grad(*args)
+g1 = m.flat_grad().cpu().numpy().astype(np.float64).copy()
+# the reference's call sequence: hT comes back too (the tails ride in the forward's launch)
+m._step_counter = 3
+m.zero_grad()
+hT, loss2 = m(*args)
+loss2.backward()
+g2 = np.concatenate([p.grad.detach().cpu().numpy().reshape(-1) for p in m.parameters()]).astype(np.float64)
+np.save({out!r}, np.concatenate([[float(loss), float(loss2)], hT.detach().cpu().numpy().reshape(-1).astype(np.float64), g1, g2]))
+'''
+
+
+@pytest.mark.parametrize('B', [100, 200, 7])
+def test_wave_per_item_ode_kernels_match_the_tiles(tmp_path, B):
+    """round 6, njode_chain_seg.h: the segment plan's ODE kernels with one wave per item (the default up
+    to 4 096 items + paths) against the 16-chain tiles over four waves, dropout ON -- the same keep
+    masks, so loss, hT and gradient agree to fp32 summation order on the fused step and on the
+    reference's call sequence (model(...); loss.backward()).  The ODE weight gradients of the new
+    route come from the lockstep plan's (step, path) pair kernel on the stored adjoints."""
+    res = {}
+    for tag, env_extra in (('items', {}), ('tiles', {'NJODE_SEG_CHAIN_MAX': '0'})):
+        out = str(tmp_path / (tag + '_seg.npy'))
+        p = subprocess.run([sys.executable, '-c', _SNIPPET_SEG.format(tests=TESTS, repo=REPO, out=out, B=B)],
+                           env=dict(os.environ, **env_extra), cwd=REPO, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-3000:]
+        res[tag] = np.load(out)
+    a, t = res['items'], res['tiles']
+    assert np.isfinite(a).all() and abs(a[0]) > 0
+    n_h = B * 10
+    n_p = (a.size - 2 - n_h) // 2
+    assert a[0] == pytest.approx(t[0], rel=2e-5) and a[1] == pytest.approx(t[1], rel=2e-5)
+    np.testing.assert_allclose(a[2:2 + n_h], t[2:2 + n_h], atol=2e-5, rtol=1e-4)
+    assert rel_l2(a[2 + n_h:2 + n_h + n_p], t[2 + n_h:2 + n_h + n_p]) < 1e-4
+    assert rel_l2(a[2 + n_h + n_p:], t[2 + n_h + n_p:]) < 1e-4
+    # both routes of the new kernels: the same step
+    assert a[0] == pytest.approx(a[1], rel=1e-6)
+    assert rel_l2(a[2 + n_h:2 + n_h + n_p], a[2 + n_h + n_p:]) < 1e-5
