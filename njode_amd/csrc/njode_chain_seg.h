@@ -82,6 +82,12 @@ __device__ __forceinline__ void seg_fwd_chain_wave(const KArgs& a, int tails, in
       a.lam_traj[((size_t)k * a.B + b) * H + q] = 0.0f;
     }
     for (int i = lane; i < n; i += 64) a.src_row[(size_t)(kbeg + i) * a.B + b] = -1;
+    // ... and so must the stored activations be that the pair kernel reads back (0 * NaN is NaN)
+    for (int s = 0; s < n; ++s) {
+      float* rec = a.act + ((size_t)(kbeg + s) * a.B + b) * CHAIN_ACT_FLOATS;
+      rec[lane] = 0.0f;
+      rec[64 + lane] = 0.0f;
+    }
   }
   if (is_tail && !tails) return;
 

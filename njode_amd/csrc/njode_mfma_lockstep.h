@@ -737,6 +737,8 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_pairs_mfma(KArgs a) {
   }
   const long long n_pairs = (long long)a.K * a.B;
   const long long n_tiles = (n_pairs + 15) / 16;
+  // stored hidden activations of every pair, when the saving forward kept them (wave-uniform)
+  const float* const rec = a.chain ? a.lact : (a.seg_chain ? a.act : nullptr);
   for (long long tile = wave; tile < n_tiles; tile += n_waves) {
     const long long p0 = tile * 16 + c;
     const bool valid = p0 < n_pairs;
@@ -759,6 +761,37 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_pairs_mfma(KArgs a) {
     float b0[M::Q0], a1[M::Q1], a2[M::Q1];
     in0_fill<C, 0>(b0, h, tx, tau, t - tau, g);
     uint32_t k1 = 0, k2 = 0;
+    if (rec) {
+      // (round 6) the saving forward was a wave-per-path / wave-per-item kernel (njode_chain.h,
+      // njode_chain_seg.h): it stored both hidden activations of every (step, path) pair, one unit per
+      // lane in the DPP layout -- unit 4 q + g in lane 16 g + q, i.e. THIS lane's Q1 units are
+      // consecutive floats.  No recomputation (140 of this tile's ~440 matrix instructions) and no
+      // mask draws: a dropped unit is stored as -0.0f.
+      static_assert(M::Q1 <= 16, "one lane group's units fit its 16 lanes");
+      const float* r1 = rec + ((size_t)p * 2) * 64 + 16 * g;
+      float v1[16], v2[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 x1 = *(const f32x4*)(r1 + 4 * j), x2 = *(const f32x4*)(r1 + 64 + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v1[4 * j + e] = x1[e];
+          v2[4 * j + e] = x2[e];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < M::Q1; ++q) {
+        a1[q] = v1[q];
+        a2[q] = v2[q];
+        if constexpr (DROP) {
+          k1 |= (uint32_t)(__float_as_uint(v1[q]) != 0x80000000u) << q;
+          k2 |= (uint32_t)(__float_as_uint(v2[q]) != 0x80000000u) << q;
+        }
+      }
+      constexpr int QB = M::W / 4, GB = M::W % 4;   // the bias unit of the next layer's input
+      a1[QB] = g == GB ? 1.0f : a1[QB];
+      a2[QB] = g == GB ? 1.0f : a2[QB];
+    } else {
     if constexpr (DROP) {
       const unsigned long long gid = a.gid0 + b;
       uint32_t st = drop_state(a.dc, (uint32_t)gid, (uint32_t)(gid >> 32) + 0x5bd1e995u * (g + 1),
@@ -782,6 +815,9 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_pairs_mfma(KArgs a) {
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.a2(mt, q), a1[q], acc[mt]);
     hidden_from_acc<C, DROP>(acc, a2, k2, a.dc.inv_keep, g);
+    }
+    F.begin();
+    f32x4 acc[M::MT1];
     // layer 3
     img_write<M::QH>(img_d, d3, g, c);
     img_write<M::Q1>(img_a, a2, g, c);

@@ -21,6 +21,11 @@ from golden_util import GOLDEN_DIR, Golden
 
 CASES = ['g5_masked', 'g5_full', 'g5_w200']
 FACTOR = 2.0
+# Gradients: where the exact discrete adjoint on stored activations is CLOSER to
+# float64 than the reference's fp32 autograd, the bound says so.  Round 6, wave-per-path kernels with
+# two-accumulator dot products: g5_masked 0.47 - 0.70, g5_full 0.93 - 0.96 (profiles/r06_f64_truth.txt);
+# g5_w200 runs the shape-generic kernels (0.85 - 1.67, round 5).
+GRAD_FACTOR = {'g5_masked': 1.0, 'g5_full': 1.25, 'g5_w200': 2.0}
 
 
 def _truth():
@@ -62,13 +67,13 @@ def test_hip_is_as_close_to_float64_as_the_reference_is(name):
     rows = g['path_rows'] if 'path_rows' in g else slice(None)
     rep, bad = {'fixture': name}, []
 
-    def check(key, got, ref32, truth, floor_max=0.0, floor_l2=0.0):
+    def check(key, got, ref32, truth, floor_max=0.0, floor_l2=0.0, factor=FACTOR, max_too=True):
         h_max, h_l2 = _errs(got, truth)
         r_max, r_l2 = _errs(ref32, truth)
         rep[key] = {'hip_max': h_max, 'ref_max': r_max, 'hip_l2': h_l2, 'ref_l2': r_l2}
-        if h_max > FACTOR * r_max + floor_max:
+        if max_too and h_max > factor * r_max + floor_max:
             bad.append((key, 'max', h_max, r_max))
-        if h_l2 > FACTOR * r_l2 + floor_l2:
+        if h_l2 > factor * r_l2 + floor_l2:
             bad.append((key, 'l2', h_l2, r_l2))
 
     check('path_y', path_y.cpu().numpy()[rows], g['path_y'], t[name + '/path_y'])
@@ -92,7 +97,10 @@ def test_hip_is_as_close_to_float64_as_the_reference_is(name):
         # per tensor, with a floor of one fp32 ulp of the tensor's largest entry (tiny bias
         # gradients: either side is then exact to rounding)
         ulp = eps * float(np.abs(truth).max())
+        # (L2 against the tightened per-fixture factor; the single worst entry against the general one)
         check('grad/' + k, got[k], ref32, truth, floor_max=4 * ulp, floor_l2=ulp * np.sqrt(truth.size))
+        check('grad/' + k, got[k], ref32, truth, floor_l2=ulp * np.sqrt(truth.size), factor=GRAD_FACTOR[name],
+              max_too=False)
         r = rep['grad/' + k]
         worst = max(worst, r['hip_l2'] / max(r['ref_l2'], 1e-300))
     rep['worst_gradient_l2_ratio'] = worst

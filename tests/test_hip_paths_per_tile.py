@@ -175,3 +175,44 @@ def test_wave_per_item_ode_kernels_match_the_tiles(tmp_path, B):
     # both routes of the new kernels: the same step
     assert a[0] == pytest.approx(a[1], rel=1e-6)
     assert rel_l2(a[2 + n_h:2 + n_h + n_p], a[2 + n_h + n_p:]) < 1e-5
+
+
+@pytest.mark.parametrize('shape', ['demo_b100', 'masked_b37'])
+def test_a_step_reads_nothing_it_did_not_write(shape):
+    """The workspace is the caller's and arrives uninitialised.  The wave-per-item route hands (step, path)
+    pairs to the lockstep plan's weight-gradient kernel, which reads the stored activations of EVERY pair
+    -- also of the pairs behind a path's last observation, which no item owns: their records must have
+    been filled (0 x NaN is NaN; found by a flaky resume test in round 6).  Every pooled workspace is
+    poisoned with NaN bit patterns between two identical steps: same loss, same gradient, bit for bit."""
+    import torch
+    from hip_util import bs_batch, demo_cfg, hip_model
+    from njode_amd import models, synthetic_physionet
+    if shape == 'demo_b100':
+        b, meta = bs_batch(100, seed=11, obs_perc=0.05)        # (long tails behind the last observations)
+        m = hip_model(demo_cfg(dropout=0.1)).train()
+        args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'], meta['maturity'],
+                b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+        kw = {}
+    else:
+        NN = ((50, 'tanh'), (50, 'tanh'))
+        cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
+                   use_rnn=False, bias=True, dropout_rate=0.1, options={'masked': True, 'device_outputs': True})
+        b = synthetic_physionet.make_batch(batch_size=37, n_grid=60, n_obs_range=(3, 9), seed=3)
+        torch.manual_seed(0)
+        m = models.NJODE(**cfg).cuda().train()
+        args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), b['delta_t'], b['T'],
+                b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
+        kw = {'M': b['M'].cuda()}
+    res = []
+    for rep in range(3):
+        m._step_counter = 3
+        _, loss = m.loss_and_grad(*args, **kw)
+        res.append((float(loss), m.flat_grad().clone()))
+        torch.cuda.synchronize()
+        for slot in m._ws_pool:                     # poison what the next step will be handed
+            if not slot[1]:
+                slot[0].fill_(0xFF)
+        torch.cuda.synchronize()
+    assert np.isfinite(res[0][0]) and bool(torch.isfinite(res[0][1]).all())
+    for r in res[1:]:
+        assert r[0] == res[0][0] and torch.equal(r[1], res[0][1])

@@ -5,7 +5,7 @@ from njode_amd import models, synthetic_physionet
 NN = ((50, 'tanh'), (50, 'tanh'))
 cfg = dict(input_size=41, hidden_size=41, output_size=41, ode_nn=NN, readout_nn=NN, enc_nn=NN,
            use_rnn=False, bias=True, dropout_rate=0.0, options={'masked': True, 'device_outputs': True})
-b = synthetic_physionet.make_batch(batch_size=50, seed=0, n_obs_range=(1, 2))
+b = synthetic_physionet.make_batch(batch_size=50, seed=0, n_obs_range=(30, 100))
 torch.manual_seed(0)
 m = models.NJODE(**cfg).cuda().train()
 args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), b['delta_t'],
