@@ -160,7 +160,7 @@ def cpu_baseline(meta_dt, T):
             'cpu_model': _cpu_model_name(), 'host_cpu_count': os.cpu_count()}
 
 
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r05_final_pmc_summary.json')
+PMC_SUMMARY_GLOB = os.path.join(ROOT, 'profiles', 'r*_final_pmc_summary.json')   # newest round first
 
 
 def _lib_sha256():
@@ -182,6 +182,7 @@ def measured_traffic(kernel, n_paths, dropout):
     """HBM bytes per launch of `kernel` as MEASURED on this build: profiles/
     r05_final_pmc_summary.json is written by tools/summarize_pmc.py from `rocprofv3 --pmc
     FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `python bench.py` (recipe: profiles/README.md),
+    (any round's profiles/r*_final_pmc_summary.json)
     and records the workload it was taken on AND the sha256 of the library it was taken with.
     Returned only when that workload is the one being benchmarked on that very library, else
     None (a counter cannot be collected inside this process; after any kernel change the
@@ -191,10 +192,18 @@ def measured_traffic(kernel, n_paths, dropout):
     pattern (one dword per lane, 256 B per wave access): the forward's WRITE_SIZE equals the
     bytes it stores (activations + checkpoints, 844 MB), and the backward, which reads those
     same bytes back, shows FETCH_SIZE = 0.56x of them.  Reported: 2 x FETCH_SIZE + WRITE_SIZE."""
-    try:
-        with open(PMC_SUMMARY) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
+    import glob
+    d, sha = None, _lib_sha256()
+    for path in sorted(glob.glob(PMC_SUMMARY_GLOB), reverse=True):
+        try:
+            with open(path) as f:
+                cand = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if cand.get('_workload', {}).get('lib_sha256') == sha:   # the counters of THIS library
+            d = cand
+            break
+    if d is None:
         return None, None
     wl = d.get('_workload', {})
     if wl.get('paths_per_gpu') != n_paths or abs(wl.get('dropout', -1) - dropout) > 1e-12:

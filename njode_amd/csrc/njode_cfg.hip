@@ -416,7 +416,7 @@ template <class CC> static void lock_pack_frags(const KArgs& a, hipStream_t st) 
 }
 template <class CC, bool DROP> static void lock_launch_mfma(const KArgs& a, hipStream_t st) {
   if constexpr (HAS_CHAIN) {
-    if (a.chain && !a.want_path) {
+    if (a.chain && !(a.want_path && DROP)) {   // (prediction calls: dropout-free ones)
       (void)NJ_CAT(njode_chain_forward_, NJ_ID)(a, DROP, st);
       return;
     }
@@ -444,8 +444,9 @@ template <bool DROP> static hipError_t lock_t(KArgs a, bool path, bool loss, int
   a.want_loss = loss ? 1 : 0;
   if (ode == ODE_MFMA && HAS_MFMA_LOCK) {
     // (the wave-per-path kernels read the flat parameter vector themselves)
-    if (!(HAS_CHAIN && a.chain && !a.want_path)) lock_pack_frags<C>(a, st);
-    ProfScope ps(HAS_CHAIN && a.chain && !a.want_path ? "k_paths_fwd_chain" : "k_paths_fwd_mfma", st);
+    const bool chain = HAS_CHAIN && a.chain && !(a.want_path && DROP);
+    if (!chain) lock_pack_frags<C>(a, st);
+    ProfScope ps(chain ? "k_paths_fwd_chain" : "k_paths_fwd_mfma", st);
     lock_launch_mfma<C, DROP>(a, st);
   } else {
     ProfScope ps("k_paths_fwd", st);

@@ -350,120 +350,155 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_fwd_chain(KArgs 
       m2_n = sbits[chain_step_bits(0, a.K, b) + 1];
     }
   }
-  // The path's chain, segment by segment: the Euler steps up to the next observation are a plain
-  // counted loop (nothing in it but the step: its scalar prefetches and stores keep one shape), then
-  // the jump.  (Two observation times closer than 1e-10 dt share a step index: a segment of no steps.)
-  int k = 0;
-  for (;;) {
-    const int k_stop = k_next < a.K ? k_next : a.K;
-    for (; k < k_stop; ++k) {
-      *lt_p = h;   // state before step k
-      lt_p += lt_step;
-      *sr_p = src;
-      sr_p += sr_step;
-      // ---- Euler step k (models.py:369-377, 430-445)
-      const float dt = dt_n, t = t_n;
-      const uint64_t m1 = m1_n, m2 = m2_n;
-      {   // (unconditional, clamped index: a load under `if (k + 1 < K)` makes the loop-carried value
-          // a vector register, and the copy waits for the scalar load where it is issued)
-        const int kn = k + 1 < a.K ? k + 1 : k;
-        dt_n = sdt[kn];
-        t_n = stt[kn];
-        if constexpr (DROP) {
-          m1_n = sbits[chain_step_bits(kn, a.K, b)];
-          m2_n = sbits[chain_step_bits(kn, a.K, b) + 1];
-        }
-      }
-#ifdef NJ_CHAIN_STAMP
-      const bool ch_on = b == 0 && k == a.K / 2;
-#endif
-      CH_STAMP_DECL;
-      CH_STAMP();
-      float R[4];
-      float z = fmaf(w1td, t - tau, c1);
-      if constexpr (C::CURT) z = fmaf(w1ct, tau + (t - tau), z);
-      dpp_replicate(th, R);
-      z = dpp_dot<H>(z, R, w1h);
-      CH_STAMP();
-      const float a1l = chain_hidden<C::ACT, DROP>(z, m1, inv_keep);
-      dpp_replicate(a1l, R);
-      CH_STAMP();
-      z = dpp_dot<W>(ob2, R, w2);
-      CH_STAMP();
-      const float a2l = chain_hidden<C::ACT, DROP>(z, m2, inv_keep);
-      dpp_replicate(a2l, R);
-      CH_STAMP();
-      const float f = dpp_dot<W>(ob3, R, w3);
-      CH_STAMP();
-      la_p[0] = a1l;
-      la_p[la_2] = a2l;
-      la_p += la_step;
-      h = uH ? fmaf(dt, f, h) : 0.0f;
-      th = tanh_f(h);
-      CH_STAMP();
-      CH_STAMP_PRINT("chain fwd");
-    }
-    if (k_next > a.K) break;
-    {   // ---- jump (models.py:457-489): this path observes before step k (= k_next)
-      const int r_ = r_next;
-      const float xr = a.X[(size_t)r_ * D + jD];
-      const float mr = C::MASKED ? a.M[(size_t)r_ * D + jD] : 1.0f;
-      const float tnew = tf32[i_next];
-      uint64_t jm[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  float y_cur = 0.0f;   // the current prediction, own unit (prediction calls: path_y)
+  auto euler_step = [&](int k) {   // ---- Euler step k (models.py:369-377, 430-445)
+    *lt_p = h;   // state before step k
+    lt_p += lt_step;
+    *sr_p = src;
+    sr_p += sr_step;
+    // ---- Euler step k (models.py:369-377, 430-445)
+    const float dt = dt_n, t = t_n;
+    const uint64_t m1 = m1_n, m2 = m2_n;
+    {   // (unconditional, clamped index: a load under `if (k + 1 < K)` makes the loop-carried value
+        // a vector register, and the copy waits for the scalar load where it is issued)
+      const int kn = k + 1 < a.K ? k + 1 : k;
+      dt_n = sdt[kn];
+      t_n = stt[kn];
       if constexpr (DROP) {
+        m1_n = sbits[chain_step_bits(kn, a.K, b)];
+        m2_n = sbits[chain_step_bits(kn, a.K, b) + 1];
+      }
+    }
+#ifdef NJ_CHAIN_STAMP
+    const bool ch_on = b == 0 && k == a.K / 2;
+#endif
+    CH_STAMP_DECL;
+    CH_STAMP();
+    float R[4];
+    float z = fmaf(w1td, t - tau, c1);
+    if constexpr (C::CURT) z = fmaf(w1ct, tau + (t - tau), z);
+    dpp_replicate(th, R);
+    z = dpp_dot<H>(z, R, w1h);
+    CH_STAMP();
+    const float a1l = chain_hidden<C::ACT, DROP>(z, m1, inv_keep);
+    dpp_replicate(a1l, R);
+    CH_STAMP();
+    z = dpp_dot<W>(ob2, R, w2);
+    CH_STAMP();
+    const float a2l = chain_hidden<C::ACT, DROP>(z, m2, inv_keep);
+    dpp_replicate(a2l, R);
+    CH_STAMP();
+    const float f = dpp_dot<W>(ob3, R, w3);
+    CH_STAMP();
+    la_p[0] = a1l;
+    la_p[la_2] = a2l;
+    la_p += la_step;
+    h = uH ? fmaf(dt, f, h) : 0.0f;
+    th = tanh_f(h);
+    CH_STAMP();
+    CH_STAMP_PRINT("chain fwd");
+  };
+  auto jump = [&]() {   // ---- jump (models.py:457-489): this path observes before step k_next
+    const int r_ = r_next;
+    const float xr = a.X[(size_t)r_ * D + jD];
+    const float mr = C::MASKED ? a.M[(size_t)r_ * D + jD] : 1.0f;
+    const float tnew = tf32[i_next];
+    uint64_t jm[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    if constexpr (DROP) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-          jm[e][0] = rbits[chain_row_bits(r_, e)];
-          jm[e][1] = rbits[chain_row_bits(r_, e) + 1];
-        }
+      for (int e = 0; e < 3; ++e) {
+        jm[e][0] = rbits[chain_row_bits(r_, e)];
+        jm[e][1] = rbits[chain_row_bits(r_, e) + 1];
       }
-      float* ja_p = a.jact + (size_t)r_ * CHAIN_JACT_FLOATS + lane;
-      // the path's next row, loaded beside the jump
-      ++cur;
-      load_next();
-      if (SAVE && uH) a.h_end[(size_t)r_ * H + u] = h;
+    }
+    float* ja_p = a.jact + (size_t)r_ * CHAIN_JACT_FLOATS + lane;
+    // the path's next row, loaded beside the jump
+    ++cur;
+    load_next();
+    if (SAVE && uH) a.h_end[(size_t)r_ * H + u] = h;
+    float a1l, a2l;
+    const float ybj = readout(h, th, jm[0][0], jm[0][1], a1l, a2l);   // y_bj = readout(h)
+    if (SAVE) {
+      ja_p[0] = a1l;
+      ja_p[64] = a2l;
+    }
+    const float x = uD ? xr : 0.0f, m = uD ? mr : 0.0f;
+    const float xin = C::MASKED ? x * m + (1.0f - m) * ybj : x;
+    const float hn = encode(xin, uD ? tanh_f(xin) : 0.0f, m, jm[1][0], jm[1][1], a1l, a2l);
+    if (SAVE) {
+      ja_p[128] = a1l;
+      ja_p[192] = a2l;
+    }
+    const float thn = tanh_f(hn);
+    const float yn = readout(hn, thn, jm[2][0], jm[2][1], a1l, a2l);
+    if (SAVE) {
+      ja_p[256] = a1l;
+      ja_p[320] = a2l;
+      if (uO) {
+        a.y_row[(size_t)r_ * DO + u] = yn;
+        a.ybj_row[(size_t)r_ * DO + u] = ybj;
+      }
+    }
+    if (LOSS) {   // compute_loss (models.py:76-110) of this row
+      const float e = x - yn;
+      const float f = a.loss_easy ? (ybj - x) : (ybj - yn);
+      const float sa = chain_sum<D>(m * e * e);
+      const float sb = chain_sum<D>(m * f * f);
+      const float scale = a.inv_batch * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
+      const float na = sqrtf(sa + 1e-10f), nb = sqrtf(sb + 1e-10f);
+      const float ca = a.loss_easy ? a.weight : 2.0f * a.weight;
+      const float cb = a.loss_easy ? (1.0f - a.weight) : 2.0f * (1.0f - a.weight);
+      const float s = ca * na + cb * nb;
+      loss_acc += s * s * scale;
+    }
+    // commit (models.py:463-489)
+    h = hn;
+    th = thn;
+    tx = uD ? tanh_f(C::MASKED ? yn : x) : 0.0f;
+    tau = tnew;
+    src = r_;
+    c1 = segment_c1(tx, tau);
+    y_cur = yn;
+  };
+  if (a.want_path) {
+    // Prediction calls (return_path; evaluate / get_pred): the batch's LOCKSTEP row structure -- a row
+    // of (h, readout(h)) at t = 0, behind every Euler step and at every observation TIME of the batch,
+    // whether this path observes then or not (models.py:423-426, 442-445, 491-494) -- so the times are
+    // walked one by one and the readout runs after every step.  (Dropout-free calls only: njode_cfg.hip.)
+    const int DOp = DO;
+    int row = 0, i_all = 0;
+    auto write_row = [&]() {
+      if (uH) a.path_h[((size_t)row * a.B + b) * H + u] = h;
+      if (uO) a.path_y[((size_t)row * a.B + b) * DOp + u] = y_cur;
+      ++row;
+    };
+    {
       float a1l, a2l;
-      const float ybj = readout(h, th, jm[0][0], jm[0][1], a1l, a2l);   // y_bj = readout(h)
-      if (SAVE) {
-        ja_p[0] = a1l;
-        ja_p[64] = a2l;
+      y_cur = readout(h, th, 0, 0, a1l, a2l);
+    }
+    write_row();
+    for (int k = 0;; ++k) {
+      while (i_all < a.n_times && kjump[i_all] == k) {
+        if (k_next == k && i_next == i_all) jump();
+        write_row();
+        ++i_all;
       }
-      const float x = uD ? xr : 0.0f, m = uD ? mr : 0.0f;
-      const float xin = C::MASKED ? x * m + (1.0f - m) * ybj : x;
-      const float hn = encode(xin, uD ? tanh_f(xin) : 0.0f, m, jm[1][0], jm[1][1], a1l, a2l);
-      if (SAVE) {
-        ja_p[128] = a1l;
-        ja_p[192] = a2l;
-      }
-      const float thn = tanh_f(hn);
-      const float yn = readout(hn, thn, jm[2][0], jm[2][1], a1l, a2l);
-      if (SAVE) {
-        ja_p[256] = a1l;
-        ja_p[320] = a2l;
-        if (uO) {
-          a.y_row[(size_t)r_ * DO + u] = yn;
-          a.ybj_row[(size_t)r_ * DO + u] = ybj;
-        }
-      }
-      if (LOSS) {   // compute_loss (models.py:76-110) of this row
-        const float e = x - yn;
-        const float f = a.loss_easy ? (ybj - x) : (ybj - yn);
-        const float sa = chain_sum<D>(m * e * e);
-        const float sb = chain_sum<D>(m * f * f);
-        const float scale = a.inv_batch * __builtin_amdgcn_rcpf((float)a.n_obs_ot[b]);
-        const float na = sqrtf(sa + 1e-10f), nb = sqrtf(sb + 1e-10f);
-        const float ca = a.loss_easy ? a.weight : 2.0f * a.weight;
-        const float cb = a.loss_easy ? (1.0f - a.weight) : 2.0f * (1.0f - a.weight);
-        const float s = ca * na + cb * nb;
-        loss_acc += s * s * scale;
-      }
-      // commit (models.py:463-489)
-      h = hn;
-      th = thn;
-      tx = uD ? tanh_f(C::MASKED ? yn : x) : 0.0f;
-      tau = tnew;
-      src = r_;
-      c1 = segment_c1(tx, tau);
+      if (k >= a.K) break;
+      euler_step(k);
+      float a1l, a2l;
+      y_cur = readout(h, th, 0, 0, a1l, a2l);
+      write_row();
+    }
+  } else {
+    // The path's chain, segment by segment: the Euler steps up to the next observation are a plain
+    // counted loop (nothing in it but the step: its scalar prefetches and stores keep one shape), then
+    // the jump.  (Two observation times closer than 1e-10 dt share a step index: a segment of no steps.)
+    int k = 0;
+    for (;;) {
+      const int k_stop = k_next < a.K ? k_next : a.K;
+      for (; k < k_stop; ++k) euler_step(k);
+      if (k_next > a.K) break;
+      jump();
     }
   }
   *lt_p = h;   // the final state: ltraj[K]

@@ -6,11 +6,14 @@ every prediction back as an input (models.py:465-467, 483-484), so two correct f
 drift apart by more than a plain 1e-5; what a tolerance against the reference's fp32 output
 cannot tell is WHICH of the two is off.  Here both are measured against the float64 result:
 
-    err(HIP fp32, f64)  <=  2 x err(reference fp32, f64)        (max-abs and L2)
+    err(HIP fp32, f64)  <=  1.5 x err(reference fp32, f64)      (max-abs and L2; round 5: 2 x)
 
 on the prediction path, hT, the loss and every gradient tensor -- i.e. the HIP result is no
 further from the truth than the reference itself is (factor 2: two fp32 evaluations of the same
-recursion round differently, neither is privileged).  The CPU half (not gpu) checks the fixture
+recursion round differently, neither is privileged).  Round 6: the prediction calls of the specialised
+masked shapes run the wave-per-path forward (njode_chain.h; two-accumulator fma chains), which ends
+0.65 x (g5_masked) / 0.98 x (g5_full) the reference's distance from float64 where the matrix-core
+lockstep forward ended 1.84 x / 1.40 x (profiles/r06_f64_truth.txt): FACTOR 2 -> 1.5.  The CPU half (not gpu) checks the fixture
 against the fp32 goldens, so the truth cannot silently be something else.
 """
 import numpy as np
@@ -20,7 +23,7 @@ import torch
 from golden_util import GOLDEN_DIR, Golden
 
 CASES = ['g5_masked', 'g5_full', 'g5_w200']
-FACTOR = 2.0
+FACTOR = 1.5      # (round 6: 2.0 -> 1.5; measured 0.65 / 0.75 (g5_masked), 0.98 / 1.05 (g5_full), 0.81 / 0.98 (g5_w200))
 # Gradients: where the exact discrete adjoint on stored activations is CLOSER to
 # float64 than the reference's fp32 autograd, the bound says so.  Round 6, wave-per-path kernels with
 # two-accumulator dot products: g5_masked 0.47 - 0.70, g5_full 0.93 - 0.96 (profiles/r06_f64_truth.txt);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the round's judged artifacts from gpurun_out/ (scratch) into profiles/ (tracked)
 set -e
-R=${1:-r05}
+R=${1:-r06}
 cp gpurun_out/${R}_final_bench.json profiles/${R}_final_bench.json
 cp gpurun_out/${R}_final_kernel_stats.csv profiles/${R}_final_kernel_stats.csv
 cp gpurun_out/${R}_final_pmc_summary.json profiles/${R}_final_pmc_summary.json

@@ -4,7 +4,7 @@
 #   1. the GPU test suite; 2. rocprofv3 stats + PMC passes of `python3 bench.py` -> <R>_final_*;
 #   3. the PMC summary goes to profiles/ FIRST, so that 4. `python bench.py` (the driver's command)
 #   finds the counters of this very library (roofline.traffic); 5. timelines and side benches.
-R=${1:-r05}
+R=${1:-r06}
 set -o pipefail
 # (the suite's verdict travels with the artifacts; profiles of a library whose suite is red are not
 # evidence: abort before they are produced)
@@ -18,8 +18,9 @@ python bench.py > gpurun_out/${R}_final_bench.json 2> gpurun_out/${R}_final_benc
 head -c 300 gpurun_out/${R}_final_bench.json; echo
 bash tools/trace_step.sh ${R}_final_trace > /dev/null; head -24 gpurun_out/${R}_final_trace_trace.txt
 bash tools/trace_autograd.sh ${R}_autograd > gpurun_out/${R}_autograd_route_timeline.txt 2>&1
-DROPOUT=0.1 python tools/bench_physionet.py 2>/dev/null | grep config5 > gpurun_out/${R}_config5_kernels.jsonl
-DROPOUT=0.0 python tools/bench_physionet.py 2>/dev/null | grep config5 >> gpurun_out/${R}_config5_kernels.jsonl
+DROPOUT=0.1 BATCHES=50,800,1000,2048 python tools/bench_physionet.py 2>/dev/null | grep config5 > gpurun_out/${R}_config5_kernels.jsonl
+DROPOUT=0.0 BATCHES=50,800,1000,2048 python tools/bench_physionet.py 2>/dev/null | grep config5 >> gpurun_out/${R}_config5_kernels.jsonl
+NJODE_CHAIN_MAX=0 DROPOUT=0.1 BATCHES=50,800,1000,2048 python tools/bench_physionet.py 2>/dev/null | grep config5 | sed 's/config5-kernels/config5-kernels (NJODE_CHAIN_MAX=0: the matrix-core tiles)/' >> gpurun_out/${R}_config5_kernels.jsonl
 bash tools/small_stats.sh ${R}_small100 100 > gpurun_out/${R}_small_batch_kernels.txt; bash tools/small_stats.sh ${R}_small200 200 >> gpurun_out/${R}_small_batch_kernels.txt
 python tools/bench_generic.py 2>/dev/null > gpurun_out/${R}_generic_bench.jsonl
 python tools/bench_configs.py 2>/dev/null > gpurun_out/${R}_configs_sweep.jsonl

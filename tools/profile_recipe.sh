@@ -13,7 +13,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="$ROOT/bench.py --no-cpu-baseline --no-small-batch --no-autograd-route"
+BENCH="$ROOT/bench.py --no-cpu-baseline --no-small-batch --no-autograd-route --no-config5"
 REGEX='k_ode|k_jump|k_encode|k_reduce|k_adam|k_pack|k_row_time|k_dense|k_traj|k_sum'
 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $BENCH --steps 20 \

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/bench.py \
-  --no-cpu-baseline --no-small-batch --no-kernel-timing --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/trace.err
+  --no-cpu-baseline --no-small-batch --no-config5 --no-kernel-timing --steps 6 --warmup 2 > $OUT/bench.json 2> $OUT/trace.err
 cd $ROOT
 python3 - "$OUT" > gpurun_out/${TAG}_trace.txt <<'PY'
 import csv, glob, sys
