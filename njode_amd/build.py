@@ -143,7 +143,7 @@ def build(force=False, jobs=None, verbose=True):
                     'njode_mfma.h', 'njode_mfma_rows.h', 'njode_lockstep_bwd.h',
                     'njode_mfma_lockstep.h', 'njode_mfma_split.h', 'njode_ode2.h',
                     'njode_mfma_lock4.h', 'njode_plan.h')] + [hdr]
-    chain_deps = kernel_deps + [os.path.join(CSRC, n) for n in ('njode_chain.h', 'njode_dpp.h', 'njode_chain_seg.h')]
+    chain_deps = kernel_deps + [os.path.join(CSRC, n) for n in ('njode_chain.h', 'njode_dpp.h', 'njode_chain_seg.h', 'njode_chain_dw.h')]
     gen_deps = [os.path.join(CSRC, n) for n in
                 ('njode_gen.hip', 'njode_gen.h', 'njode_gen_seg.h', 'njode_gen_host.h', 'njode_device.h',
                  'njode_error.h')] + [hdr]

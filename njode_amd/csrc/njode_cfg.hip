@@ -11,6 +11,7 @@
 #if NJ_PART >= 4
 #include "njode_chain.h"
 #include "njode_chain_seg.h"
+#include "njode_chain_dw.h"
 #endif
 
 #define NJ_CAT_(a, b) a##b
@@ -44,6 +45,9 @@ constexpr bool HAS_Q4 = HAS_MFMA_SWEEP && Q4Ok<C>::value;
 constexpr bool HAS_CHAIN = HAS_Q4 && ChainOk<C>::value;
 hipError_t NJ_CAT(njode_chain_forward_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
+// dW of the ODE network from the wave-per-chain sweeps' records (njode_chain_dw.h; part 5); false: not
+// launched (no stored deltas / segment sums for this call) -- k_ode_dw_pairs_mfma then
+bool NJ_CAT(njode_chain_dw_, NJ_ID)(const KArgs& a, hipStream_t st);
 // the segment plan's ODE kernels with one wave per item (njode_chain_seg.h; KArgs::seg_chain)
 constexpr bool HAS_SEG_CHAIN = HAS_SPLIT && HAS_MFMA_SWEEP && SegChainOk<C>::value;
 hipError_t NJ_CAT(njode_seg_chain_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, hipStream_t st);
@@ -488,7 +492,7 @@ template <class CC, bool DROP> static void lock_bwd_mfma(const KArgs& a, hipStre
       }
       if (!q4) k_paths_bwd_adj_mfma<CC, DROP><<<cdiv(a.B, 16), 64, 0, st>>>(a);
     }
-    {
+    if (!NJ_CAT(njode_chain_dw_, NJ_ID)(a, st)) {
       ProfScope ps("k_ode_dw_pairs_mfma", st);
       k_ode_dw_pairs_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
     }
@@ -605,7 +609,7 @@ hipError_t NJ_CAT(njode_seg_chain_backward_, NJ_ID)(const KArgs& a, bool drop, h
       if (drop) k_seg_bwd_chain<C, true><<<cdiv(a.n_obs, 4), 256, 0, st>>>(a);
       else k_seg_bwd_chain<C, false><<<cdiv(a.n_obs, 4), 256, 0, st>>>(a);
     }
-    {   // d loss / d ODE parameters from the stored adjoints: the lockstep plan's pair kernel
+    if (!NJ_CAT(njode_chain_dw_, NJ_ID)(a, st)) {   // d loss / d ODE parameters from the stored adjoints: the lockstep plan's pair kernel
       ProfScope ps("k_ode_dw_pairs_mfma", st);
       if (drop) k_ode_dw_pairs_mfma<C, true><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
       else k_ode_dw_pairs_mfma<C, false><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
@@ -613,6 +617,16 @@ hipError_t NJ_CAT(njode_seg_chain_backward_, NJ_ID)(const KArgs& a, bool drop, h
     return hipGetLastError();
   } else {
     return hipErrorNotSupported;
+  }
+}
+bool NJ_CAT(njode_chain_dw_, NJ_ID)(const KArgs& a, hipStream_t st) {
+  if constexpr ((HAS_CHAIN || HAS_SEG_CHAIN) && C::W < 64) {
+    if (!(a.chain || a.seg_chain) || !a.cdelta || !a.cseg || a.dw_pair_blocks <= 0) return false;
+    ProfScope ps("k_ode_dw_stored", st);
+    k_ode_dw_stored<C><<<a.dw_pair_blocks + a.dw_seg_blocks, 256, 0, st>>>(a, a.dw_pair_blocks);
+    return true;
+  } else {
+    return false;
   }
 }
 hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {

@@ -561,6 +561,9 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_bwd_adj_chain(KA
 
   float lam = (a.g_hT && uH) ? a.g_hT[(size_t)b * H + jH] : 0.0f;   // adjoint of h, own unit
   float d1acc = 0.0f;   // sum of delta1 over the steps of the segment, own unit
+  // ... and of delta1 (t - tau), tau = the time of the observation in front of the segment: the x / tau /
+  // time columns of dW1 are one outer product per SEGMENT (njode_chain_dw.h)
+  float s1acc = 0.0f, tau_s = 0.0f;
 
   // the row this path reverses next and the Euler step in front of which its jump sits
   int src = chain_sgpr(a.last_row[b]), src_k = -1;   // (scalar loops)
@@ -584,8 +587,14 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_bwd_adj_chain(KA
 
   const float* lt_p = a.ltraj + ((size_t)(a.K > 0 ? a.K - 1 : 0) * a.B + b) * H + jH;
   float* lm_p = uH ? a.lam_traj + ((size_t)(a.K > 0 ? a.K - 1 : 0) * a.B + b) * H + jH : a.trash + threadIdx.x;
+  // delta1 | delta2 of every step, for the pair dW kernel (a.cdelta null: it recomputes them)
+  float* ld_p = a.cdelta ? a.cdelta + ((size_t)(a.K > 0 ? a.K - 1 : 0) * a.B + b) * CHAIN_ACT_FLOATS + lane
+                         : a.trash + threadIdx.x;
+  const size_t ld_back = a.cdelta ? (size_t)a.B * CHAIN_ACT_FLOATS : 0;
   const size_t lt_back = (size_t)a.B * H, lm_back = uH ? lt_back : 0;
-  const cfp sdt = as_cfp(a.step_dt);
+  const cfp sdt = as_cfp(a.step_dt), stt = as_cfp(a.step_t), tf32 = as_cfp(a.time_f32);
+  float* const cs_base = a.cseg ? a.cseg + lane : a.trash + threadIdx.x;
+  const size_t cs_rec = a.cseg ? CHAIN_ACT_FLOATS : 0;
   const float* la_p = a.lact + ((size_t)(a.K > 0 ? a.K - 1 : 0) * a.B + b) * CHAIN_ACT_FLOATS + lane;
   const size_t la_back = (size_t)a.B * CHAIN_ACT_FLOATS;
   const float* const lt_0 = a.ltraj + (size_t)b * H + jH;
@@ -612,18 +621,20 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_bwd_adj_chain(KA
   }
   float h_cur = 0.0f;
   float dt_n = a.K > 0 ? sdt[a.K - 1] : 0.0f;   // (scalar cache, one step ahead)
+  float t_n = a.K > 0 ? stt[a.K - 1] : 0.0f;
 
   // ---- reverse Euler step k (the forward's hidden activations: no recompute)
   auto euler_step = [&](auto SET, int k) {
     constexpr int S_ = decltype(SET)::value;
     float hk = hb[S_], a1s = a1b[S_], a2s = a2b[S_];
-    const float dt = dt_n;
+    const float dt = dt_n, tdiff = t_n - tau_s;
     // the set is consumed HERE, in front of the loads that refill it: whatever wait the compiler
     // places for it then covers loads that are at least one step old, never the ones issued below
     asm volatile("" : "+v"(hk), "+v"(a1s), "+v"(a2s));
     __builtin_amdgcn_sched_barrier(0);
     fetch(SET);   // (unconditional: steps 1 and 0 re-read step 0's record)
     dt_n = sdt[k > 0 ? k - 1 : 0];
+    t_n = stt[k > 0 ? k - 1 : 0];
     __builtin_amdgcn_sched_barrier(0);
 #ifdef NJ_CHAIN_STAMP
     const bool ch_on = b == 0 && k == a.K / 2;
@@ -639,12 +650,17 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_bwd_adj_chain(KA
     CH_STAMP();
     float g = dpp_dot<H>(0.0f, R, w3t);
     CH_STAMP();
-    dpp_replicate(chain_delta<C::ACT, DROP>(g, a2s, inv_keep, keepf), R);
+    const float d2 = chain_delta<C::ACT, DROP>(g, a2s, inv_keep, keepf);
+    dpp_replicate(d2, R);
     CH_STAMP();
     g = dpp_dot<W>(0.0f, R, w2t);
     CH_STAMP();
     const float d1 = chain_delta<C::ACT, DROP>(g, a1s, inv_keep, keepf);
+    ld_p[0] = d1;
+    ld_p[64] = d2;   // (without records: 64 floats further into the scratch row)
+    ld_p -= ld_back;
     d1acc += d1;
+    s1acc = fmaf(d1, tdiff, s1acc);
     dpp_replicate(d1, R);
     CH_STAMP();
     const float din = dpp_dot<W>(0.0f, R, w1t);
@@ -661,6 +677,7 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_bwd_adj_chain(KA
   int k = a.K;   // steps k .. K-1 are reversed
   for (;;) {
     const int k_stop = src >= 0 ? src_k : 0;
+    tau_s = src >= 0 ? tf32[t_of_row[src]] : 0.0f;
     int kk = k - 1;
     if (kk >= k_stop && (kk & 1)) {
       euler_step(Set1{}, kk);
@@ -673,6 +690,12 @@ __global__ void __launch_bounds__(64 * CHAIN_MAX_WAVES) k_paths_bwd_adj_chain(KA
     if (kk >= k_stop) euler_step(Set0{}, kk);
     if (k > k_stop) h_after = h_cur;   // (the state before step k_stop)
     k = k_stop;
+    {   // the segment's sums: behind row src, or behind the path's start
+      float* cs = cs_base + (size_t)(src >= 0 ? src : a.n_obs + b) * cs_rec;
+      cs[0] = d1acc;
+      cs[64] = s1acc;
+      s1acc = 0.0f;
+    }
     if (src < 0) break;
     {   // ---- reverse the jump applied right before step k
       const int r_ = src;

@@ -87,6 +87,11 @@ __device__ __forceinline__ void seg_fwd_chain_wave(const KArgs& a, int tails, in
       float* rec = a.act + ((size_t)(kbeg + s) * a.B + b) * CHAIN_ACT_FLOATS;
       rec[lane] = 0.0f;
       rec[64 + lane] = 0.0f;
+      if (a.cdelta) {
+        float* dr = a.cdelta + ((size_t)(kbeg + s) * a.B + b) * CHAIN_ACT_FLOATS;
+        dr[lane] = 0.0f;
+        dr[64 + lane] = 0.0f;
+      }
     }
   }
   if (is_tail && !tails) return;
@@ -208,8 +213,14 @@ __global__ void __launch_bounds__(256) k_seg_bwd_chain(KArgs a) {
   typedef const int __attribute__((address_space(4)))* cip;
   const cip obs_idx = (cip)(unsigned long long)a.obs_idx,
             item_len = (cip)(unsigned long long)a.item_len, item_kbeg = (cip)(unsigned long long)a.item_kbeg;
-  const cfp sdt = as_cfp(a.step_dt);
+  const cfp sdt = as_cfp(a.step_dt), stt = as_cfp(a.step_t), tf32 = as_cfp(a.time_f32);
   const int r = wave, b = obs_idx[r], n = item_len[r], kbeg = item_kbeg[r];
+  // the item's sums S0 = sum delta1, S1 = sum delta1 (t - tau) for the x / tau / time columns of dW1
+  // (njode_chain_dw.h); tau = the time of the observation the item starts from
+  const cip item_prev = (cip)(unsigned long long)a.item_prev, t_of_row = (cip)(unsigned long long)a.t_of_row;
+  const int prev = item_prev[r];
+  const float tau_s = prev >= 0 ? tf32[t_of_row[prev >= 0 ? prev : 0]] : 0.0f;
+  float s0acc = 0.0f, s1acc = 0.0f;
 
   // transposed rows: unit layout W3[o][u] (o < H), W2[i][u]; K-split of W1^T: lane (g, c) holds
   // W1[4 n + g][D + c] (the state column c)
@@ -230,6 +241,8 @@ __global__ void __launch_bounds__(256) k_seg_bwd_chain(KArgs a) {
   const float* const lt_0 = a.ltraj + ((size_t)kbeg * a.B + b) * H + jc;
   float* lm_p = (cH && g == 0) ? a.lam_traj + ((size_t)klast * a.B + b) * H + jc : trash;
   const size_t lt_back = (size_t)a.B * H, lm_back = (cH && g == 0) ? lt_back : 0;
+  float* ld_p = a.cdelta ? a.cdelta + ((size_t)klast * a.B + b) * CHAIN_ACT_FLOATS + lane : trash;
+  const size_t ld_back = a.cdelta ? (size_t)a.B * CHAIN_ACT_FLOATS : 0;
   const float* la_p = a.act + ((size_t)klast * a.B + b) * CHAIN_ACT_FLOATS + lane;
   const float* const la_0 = a.act + ((size_t)kbeg * a.B + b) * CHAIN_ACT_FLOATS + lane;
   const size_t la_back = (size_t)a.B * CHAIN_ACT_FLOATS;
@@ -251,15 +264,16 @@ __global__ void __launch_bounds__(256) k_seg_bwd_chain(KArgs a) {
   if (n > 1) {
     if ((n - 2) & 1) fetch(Set1{}); else fetch(Set0{});
   }
-  float dt_n = n > 0 ? sdt[klast] : 0.0f;
+  float dt_n = n > 0 ? sdt[klast] : 0.0f, t_n = n > 0 ? stt[klast] : 0.0f;
   auto euler_step = [&](auto SET, int s) {   // s: the step's index within the item
     constexpr int S_ = decltype(SET)::value;
     float hk = hb[S_], a1s = a1b[S_], a2s = a2b[S_];
-    const float dt = dt_n;
+    const float dt = dt_n, tdiff = t_n - tau_s;
     asm volatile("" : "+v"(hk), "+v"(a1s), "+v"(a2s));
     __builtin_amdgcn_sched_barrier(0);
     fetch(SET);
     dt_n = sdt[kbeg + (s > 0 ? s - 1 : 0)];
+    t_n = stt[kbeg + (s > 0 ? s - 1 : 0)];
     __builtin_amdgcn_sched_barrier(0);
     const float th = cH ? tanh_f(hk) : 0.0f;
     *lm_p = lam;
@@ -268,9 +282,15 @@ __global__ void __launch_bounds__(256) k_seg_bwd_chain(KArgs a) {
     dpp_settle(d3);
     float gg = dpp_row_dot<H>(0.0f, d3, w3t);                       // W3^T delta3: unit layout
     float R[4];
-    dpp_replicate(chain_delta<C::ACT, DROP>(gg, a2s, inv_keep, keepf), R);
+    const float d2 = chain_delta<C::ACT, DROP>(gg, a2s, inv_keep, keepf);
+    dpp_replicate(d2, R);
     gg = dpp_dot<W>(0.0f, R, w2t);                                 // W2^T delta2
     float d1 = chain_delta<C::ACT, DROP>(gg, a1s, inv_keep, keepf);
+    ld_p[0] = d1;   // (for the pair dW kernel: no transposed product left in it)
+    ld_p[64] = d2;   // (without records: 64 floats further into the scratch row)
+    ld_p -= ld_back;
+    s0acc += d1;
+    s1acc = fmaf(d1, tdiff, s1acc);
     dpp_settle(d1);
     const float din = dpp_rows_sum(dpp_row_dot<NQW>(0.0f, d1, w1tp));   // W1h^T delta1, K-split
     lam = cH ? fmaf(din, 1.0f - th * th, lam) : 0.0f;
@@ -286,6 +306,11 @@ __global__ void __launch_bounds__(256) k_seg_bwd_chain(KArgs a) {
   }
   if (s >= 0) euler_step(Set0{}, s);
   if (cH && g == 0) a.lam_start[(size_t)r * H + c] = lam;
+  if (a.cseg) {
+    float* cs = a.cseg + (size_t)r * CHAIN_ACT_FLOATS + lane;
+    cs[0] = s0acc;
+    cs[64] = s1acc;
+  }
 }
 
 }  // namespace njode

@@ -155,6 +155,15 @@ struct KArgs {
   // segment plan in the latency regime (njode_chain_seg.h): one wave per item; the ODE weight
   // gradients then come from the lockstep plan's (step, path) pair kernel
   int seg_chain;
+  // ... and the deltas of the ODE network's two hidden layers at every (step, path) pair, stored by the
+  // wave-per-chain sweeps beside the adjoint ([(k B + b)][delta1 | delta2][64 lanes]; null: the pair
+  // kernel recomputes them)
+  float* cdelta;
+  // ... and per SEGMENT (lockstep plan: the steps behind row r -> record r, behind a path's start ->
+  // record n_obs + b; segment plan: item r -> record r) S0 = sum delta1 | S1 = sum delta1 (t - tau) over its
+  // steps, [64 lanes] each: the x / tau / time columns of dW1 (njode_chain_dw.h); grid of that kernel
+  float* cseg;
+  int dw_pair_blocks, dw_seg_blocks;
   // segment plan, round 5 (NJODE_ENC_FUSED=1): the one-wave role of k_ode_fwd_mixed evaluates
   // encoder(X) of an item's START row itself (njode_ode2.h); k_encode_rows_items covers the rest
   int enc_fused;

@@ -717,7 +717,9 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_pairs_mfma(KArgs a) {
   const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
   lfp img_d = (lfp)lds_raw + wv * 2 * IMG, img_a = img_d + IMG;
   lfp fimg = (lfp)lds_raw + 4 * 2 * IMG;
-  FR::stage(fimg, a.frag, threadIdx.x, 256);
+  // (stored deltas, below: no product with a weight is left in this kernel -- no fragments to stage)
+  const float* const drec = (a.chain || a.seg_chain) ? a.cdelta : nullptr;
+  if (!drec) FR::stage(fimg, a.frag, threadIdx.x, 256);
   for (int i = threadIdx.x; i < 4 * 2 * IMG; i += 256) lds_raw[i] = 0.0f;
   __syncthreads();
   FR F;
@@ -823,13 +825,38 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_pairs_mfma(KArgs a) {
     img_write<M::Q1>(img_a, a2, g, c);
     wave_lds_sync();
     dw_accumulate<M::MTH, NT1>(img_d, img_a, G3, g, c);
+    float d2[M::QW], d1[M::QW];
+    if (drec) {
+      // (round 6) the wave-per-chain sweep stored delta2 and delta1 of every pair beside its adjoint,
+      // in the activations' layout: this kernel is three outer-product accumulations and nothing else
+      // (no transposed product: 96 of the remaining ~300 matrix instructions, and no fragment table)
+      static_assert(M::QW <= 16, "one lane group's units fit its 16 lanes");
+      const float* r2 = drec + ((size_t)p * 2) * 64 + 16 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 x1 = *(const f32x4*)(r2 + 4 * j), x2 = *(const f32x4*)(r2 + 64 + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (4 * j + e < M::QW) {
+            d1[4 * j + e < M::QW ? 4 * j + e : 0] = valid ? x1[e] : 0.0f;
+            d2[4 * j + e < M::QW ? 4 * j + e : 0] = valid ? x2[e] : 0.0f;
+          }
+        }
+      }
+      wave_lds_sync();
+      // layer 2
+      img_write<M::QW>(img_d, d2, g, c);
+      img_write<M::Q1>(img_a, a1, g, c);
+      wave_lds_sync();
+      dw_accumulate<M::MT1, NT1>(img_d, img_a, G2, g, c);
+      wave_lds_sync();
+    } else {
 #pragma unroll
     for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = zero4;
 #pragma unroll
     for (int q = 0; q < M::QH; ++q)
 #pragma unroll
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b3(mt, q), d3[q], acc[mt]);
-    float d2[M::QW], d1[M::QW];
     hidden_delta<C, DROP>(acc, a2, d2, k2, a.dc.inv_keep, a.keep);
     wave_lds_sync();
     // layer 2
@@ -845,6 +872,7 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_pairs_mfma(KArgs a) {
       for (int mt = 0; mt < M::MT1; ++mt) acc[mt] = mfma4(F.b2(mt, q), d2[q], acc[mt]);
     hidden_delta<C, DROP>(acc, a1, d1, k1, a.dc.inv_keep, a.keep);
     wave_lds_sync();
+    }
     // layer 1
     img_write<M::QW>(img_d, d1, g, c);
     img_write<M::Q0>(img_a, b0, g, c);
