@@ -48,6 +48,8 @@ hipError_t NJ_CAT(njode_chain_sweep_, NJ_ID)(const KArgs& a, bool drop, hipStrea
 // dW of the ODE network from the wave-per-chain sweeps' records (njode_chain_dw.h; part 5); false: not
 // launched (no stored deltas / segment sums for this call) -- k_ode_dw_pairs_mfma then
 bool NJ_CAT(njode_chain_dw_, NJ_ID)(const KArgs& a, hipStream_t st);
+// ... the same with the segment plan's encoder pass (k_encode_rows_bwd_mfma) as a role of the launch
+bool NJ_CAT(njode_chain_dw_enc_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st);
 // the segment plan's ODE kernels with one wave per item (njode_chain_seg.h; KArgs::seg_chain)
 constexpr bool HAS_SEG_CHAIN = HAS_SPLIT && HAS_MFMA_SWEEP && SegChainOk<C>::value;
 hipError_t NJ_CAT(njode_seg_chain_forward_, NJ_ID)(const KArgs& a, bool drop, bool tails, hipStream_t st);
@@ -79,9 +81,11 @@ constexpr int ACT_FLOATS = ActSize<HAS_SPLIT, C>::value;   // stored activations
 // step's critical path once the plan is built ahead)
 template <class C, class ES, class DS>
 __global__ void k_pack_all(const float* __restrict__ P, float* __restrict__ frag, float* __restrict__ frag2,
-                           float* __restrict__ frag_enc, float* __restrict__ frag_dec, float ik) {
+                           float* __restrict__ frag_enc, float* __restrict__ frag_dec, float ik,
+                           unsigned* __restrict__ zero8) {
   constexpr int N = MF<C>::NALL * 64, NE = ES::NALL * 64, ND = DS::NALL * 64;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero8 && idx < 8) zero8[idx] = 0;   // (KArgs::plan_sync_zero)
   if (idx < N) frag[idx] = ode_frag_value<C>(P, idx, 1.0f, 1.0f);
   else if (idx < 2 * N) frag2[idx - N] = ode_frag_value<C>(P, idx - N, Ode2Scale<C>::S, ik);
   else if (idx < 2 * N + NE) pack_net_value<typename C::Enc, ES>(P + C::OFF_ENC, frag_enc, idx - 2 * N);
@@ -95,6 +99,7 @@ __global__ void k_pack_all_bits(KArgs a, int n_pack) {
   if ((int)blockIdx.x < n_pack) {
     constexpr int N = MF<C>::NALL * 64, NE = ES::NALL * 64, ND = DS::NALL * 64;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.plan_sync_zero && idx < 8) a.plan_sync_zero[idx] = 0;
     if (idx < N) a.frag[idx] = ode_frag_value<C>(a.P, idx, 1.0f, 1.0f);
     else if (idx < 2 * N) a.frag2[idx - N] = ode_frag_value<C>(a.P, idx - N, Ode2Scale<C>::S, a.dc.inv_keep);
     else if (idx < 2 * N + NE) pack_net_value<typename C::Enc, ES>(a.P + C::OFF_ENC, a.frag_enc, idx - 2 * N);
@@ -131,7 +136,8 @@ template <class CC> static void launch_pack_frags(const KArgs& a, hipStream_t st
       const int nb = (int)(work / 4 + 1 < 1024 ? work / 4 + 1 : 1024);
       k_pack_all_bits<CC, ES, DS><<<n_pack + nb, 256, 0, st>>>(a, n_pack);
     } else {
-      k_pack_all<CC, ES, DS><<<n_pack, 256, 0, st>>>(a.P, a.frag, a.frag2, a.frag_enc, a.frag_dec, a.dc.inv_keep);
+      k_pack_all<CC, ES, DS><<<n_pack, 256, 0, st>>>(a.P, a.frag, a.frag2, a.frag_enc, a.frag_dec, a.dc.inv_keep,
+                                                  a.plan_sync_zero);
     }
   }
 }
@@ -177,9 +183,10 @@ static void launch_mfma_rows_bwd(const KArgs& a, bool split, hipStream_t st) {
   if constexpr (HAS_MFMA) {
     // (defer_loss == 2, NJODE_C_ROWS_IN_FWD: the forward call already ran this pass)
     if (a.defer_loss != 2) launch_jump_rows_bwd<CC, DROP>(a, st);
-    if (HAS_SEG_CHAIN && a.seg_chain) (void)NJ_CAT(njode_seg_chain_backward_, NJ_ID)(a, DROP, st);
+    bool enc_done = false;
+    if (HAS_SEG_CHAIN && a.seg_chain) enc_done = NJ_CAT(njode_seg_chain_backward_, NJ_ID)(a, DROP, st) == hipSuccess && a.dw_enc_fused;
     else launch_ode_bwd_mfma<CC, DROP>(a, split, st);
-    {
+    if (!enc_done) {
       ProfScope ps("k_encode_rows_bwd_mfma", st);
       k_encode_rows_bwd_mfma<CC, DROP><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
     }
@@ -256,6 +263,10 @@ static hipError_t seg_forward_t(const KArgs& a, bool tails, hipStream_t st) {
                                     : (DROP && HAS_SPLIT && a.ode_split && a.dbits && !side && !bits_off &&
                                        a.n_split_fwd == a.n_blocks_fwd);
       ab.dbits_ready = bits ? 1 : 0;
+      if (ab.plan_sync_zero && s2 != st) {   // (the pack launch is not on the hosting launch's stream)
+        (void)hipMemsetAsync(ab.plan_sync_zero, 0, 8 * sizeof(unsigned), st);
+        ab.plan_sync_zero = nullptr;
+      }
       ProfScope ps("k_pack_all", s2);
       launch_pack_frags<C>(ab, s2, bits);
     }
@@ -609,7 +620,11 @@ hipError_t NJ_CAT(njode_seg_chain_backward_, NJ_ID)(const KArgs& a, bool drop, h
       if (drop) k_seg_bwd_chain<C, true><<<cdiv(a.n_obs, 4), 256, 0, st>>>(a);
       else k_seg_bwd_chain<C, false><<<cdiv(a.n_obs, 4), 256, 0, st>>>(a);
     }
-    if (!NJ_CAT(njode_chain_dw_, NJ_ID)(a, st)) {   // d loss / d ODE parameters from the stored adjoints: the lockstep plan's pair kernel
+    // d loss / d ODE parameters: from the sweep's records (with the encoder's pass in the same launch),
+    // else the lockstep plan's pair kernel on the stored adjoints
+    if (a.dw_enc_fused) {
+      if (!NJ_CAT(njode_chain_dw_enc_, NJ_ID)(a, drop, st)) return hipErrorLaunchFailure;
+    } else if (!NJ_CAT(njode_chain_dw_, NJ_ID)(a, st)) {
       ProfScope ps("k_ode_dw_pairs_mfma", st);
       if (drop) k_ode_dw_pairs_mfma<C, true><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
       else k_ode_dw_pairs_mfma<C, false><<<a.n_waves_rows / 4, 256, 0, st>>>(a);
@@ -624,6 +639,18 @@ bool NJ_CAT(njode_chain_dw_, NJ_ID)(const KArgs& a, hipStream_t st) {
     if (!(a.chain || a.seg_chain) || !a.cdelta || !a.cseg || a.dw_pair_blocks <= 0) return false;
     ProfScope ps("k_ode_dw_stored", st);
     k_ode_dw_stored<C><<<a.dw_pair_blocks + a.dw_seg_blocks, 256, 0, st>>>(a, a.dw_pair_blocks);
+    return true;
+  } else {
+    return false;
+  }
+}
+bool NJ_CAT(njode_chain_dw_enc_, NJ_ID)(const KArgs& a, bool drop, hipStream_t st) {
+  if constexpr (HAS_SEG_CHAIN && C::W < 64) {
+    if (!a.seg_chain || !a.cdelta || !a.cseg || a.dw_pair_blocks <= 0) return false;
+    ProfScope ps("k_ode_dw_stored_enc", st);
+    const int nb = a.dw_pair_blocks + a.dw_seg_blocks + a.n_waves_rows / 4;
+    if (drop) k_ode_dw_stored_enc<C, true><<<nb, 256, 0, st>>>(a, a.dw_pair_blocks, a.dw_seg_blocks);
+    else k_ode_dw_stored_enc<C, false><<<nb, 256, 0, st>>>(a, a.dw_pair_blocks, a.dw_seg_blocks);
     return true;
   } else {
     return false;

@@ -38,6 +38,7 @@
 // records of the deltas do not fit the budget (KArgs::cdelta null).
 #pragma once
 #include "njode_mfma.h"
+#include "njode_mfma_rows.h"
 
 namespace njode {
 
@@ -81,22 +82,22 @@ template <int N> NJ_DEV void dw_block_reduce(f32x4 (&G)[N], float* lds_raw, int 
   }
 }
 
+// block `block` of nbp pair blocks + nbs segment blocks
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_ode_dw_stored(KArgs a, int nbp) {
+NJ_DEV void ode_dw_stored_body(const KArgs& a, float* lds_raw, int block, int nbp, int nbs) {
   using T = ChainDw<C>;
   using NL = typename C::Ode;
   constexpr int H = C::H, W = C::W, D = C::D, IN0 = C::ODE_IN;
-  __shared__ __attribute__((aligned(16))) float lds_raw[T::NRED * 64 * 4];
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  float* slab = a.slab + (size_t)blockIdx.x * C::P + C::OFF_ODE;
+  float* slab = a.slab + (size_t)block * C::P + C::OFF_ODE;
   float *W1 = slab + NL::woff(0), *b1 = slab + NL::boff(0), *W2 = slab + NL::woff(1),
         *b2 = slab + NL::boff(1), *W3 = slab + NL::woff(2), *b3 = slab + NL::boff(2);
 
-  if ((int)blockIdx.x < nbp) {
+  if (block < nbp) {
     // =========================== pair role ===========================
-    const int wave = (int)blockIdx.x * 4 + wv, n_waves = nbp * 4;
+    const int wave = block * 4 + wv, n_waves = nbp * 4;
     const long long n_pairs = (long long)a.K * a.B;
     const int n_tiles = (int)((n_pairs + 15) / 16);
     const float* const rec = a.chain ? a.lact : a.act;
@@ -242,8 +243,7 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_stored(KArgs a, int nbp) {
 
   // =========================== segment role ===========================
   {
-    const int nbs = (int)gridDim.x - nbp;
-    const int wave = ((int)blockIdx.x - nbp) * 4 + wv, n_waves = nbs * 4;
+    const int wave = (block - nbp) * 4 + wv, n_waves = nbs * 4;
     const int n_seg = a.chain ? a.n_obs + a.B : a.n_obs;
     const int n_tiles = (n_seg + 15) / 16;
     f32x4 G[T::NS];
@@ -317,6 +317,24 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_stored(KArgs a, int nbp) {
         }
       }
   }
+}
+
+template <class C>
+__global__ void __launch_bounds__(256, 1) k_ode_dw_stored(KArgs a, int nbp) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[ChainDw<C>::NRED * 64 * 4];
+  ode_dw_stored_body<C>(a, lds_raw, (int)blockIdx.x, nbp, (int)gridDim.x - nbp);
+}
+// ... with the encoder's weight-gradient pass of the segment plan (k_encode_rows_bwd_mfma,
+// njode_mfma_rows.h) as a third role on the blocks behind: it waits for the same sweep and nothing
+// else, and at the reference's batch sizes neither pass fills the chip (B = 100: 15 + 13 us one after
+// the other)
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256, 1) k_ode_dw_stored_enc(KArgs a, int nbp, int nbs) {
+  constexpr int LDS = ChainDw<C>::NRED * 64 * 4 > EncBwdLds<C>::FLOATS ? ChainDw<C>::NRED * 64 * 4 : EncBwdLds<C>::FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds_raw[LDS];
+  const int block = (int)blockIdx.x;
+  if (block < nbp + nbs) ode_dw_stored_body<C>(a, lds_raw, block, nbp, nbs);
+  else encode_rows_bwd_body<C, DROP>(a, lds_raw, block - nbp - nbs, (int)gridDim.x - nbp - nbs);
 }
 
 }  // namespace njode

@@ -164,6 +164,10 @@ struct KArgs {
   // steps, [64 lanes] each: the x / tau / time columns of dW1 (njode_chain_dw.h); grid of that kernel
   float* cseg;
   int dw_pair_blocks, dw_seg_blocks;
+  int dw_enc_fused;   // segment plan: k_encode_rows_bwd_mfma rides in that launch (njode_chain_dw.h)
+  // the barrier counters (8 words) of the plan job this call's ODE forward hosts, when the fragment-pack
+  // launch in front of it zeroes them (same stream: no memset launch of their own); else null
+  unsigned* plan_sync_zero;
   // segment plan, round 5 (NJODE_ENC_FUSED=1): the one-wave role of k_ode_fwd_mixed evaluates
   // encoder(X) of an item's START row itself (njode_ode2.h); k_encode_rows_items covers the rest
   int enc_fused;

@@ -713,13 +713,17 @@ __global__ void __launch_bounds__(256, 2) k_jump_rows_bwd_mfma(KArgs a) {
 }
 
 // ---- D: d loss / d encoder params -----------------------------------------------------------
+// (the body as a function of the block index: njode_chain_dw.h runs it as a role of the ODE network's
+// weight-gradient launch -- both only wait for the sweep)
+template <class C> struct EncBwdLds {
+  static constexpr int FLOATS = 4 * 2 * IMG_FLOATS + EncS<C>::type::NALL * 64;
+};
 template <class C, bool DROP>
-__global__ void __launch_bounds__(256, 2) k_encode_rows_bwd_mfma(KArgs a) {
+NJ_DEV void encode_rows_bwd_body(const KArgs& a, float* lds_raw, int block, int n_blocks) {
   using S = typename EncS<C>::type;
   using NL = typename C::Enc;
-  __shared__ __attribute__((aligned(16))) float lds_raw[4 * 2 * IMG_FLOATS + S::NALL * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+  const int wave = block * 4 + wv, n_waves = n_blocks * 4;
   lfp img_d = (lfp)lds_raw + wv * 2 * IMG_FLOATS, img_a = img_d + IMG_FLOATS;
   lfp fimg = (lfp)lds_raw + 4 * 2 * IMG_FLOATS;
   LdsFrags<S>::stage(fimg, a.frag_enc, threadIdx.x, 256);
@@ -762,7 +766,12 @@ __global__ void __launch_bounds__(256, 2) k_encode_rows_bwd_mfma(KArgs a) {
   }
   static_assert(3 * GradTiles<S>::NG * 256 <= 4 * 2 * IMG_FLOATS + S::NALL * 64, "tile reduction does not fit");
   if (G.reduce_block((lfp)lds_raw, wv, lane))
-    G.template flush<NL>(a.slab + (size_t)blockIdx.x * C::P + C::OFF_ENC, g, c);
+    G.template flush<NL>(a.slab + (size_t)block * C::P + C::OFF_ENC, g, c);
+}
+template <class C, bool DROP>
+__global__ void __launch_bounds__(256, 2) k_encode_rows_bwd_mfma(KArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[EncBwdLds<C>::FLOATS];
+  encode_rows_bwd_body<C, DROP>(a, lds_raw, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace njode

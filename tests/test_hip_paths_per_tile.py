@@ -177,6 +177,35 @@ def test_wave_per_item_ode_kernels_match_the_tiles(tmp_path, B):
     assert rel_l2(a[2 + n_h:2 + n_h + n_p], a[2 + n_h + n_p:]) < 1e-5
 
 
+def test_weight_gradients_from_stored_operands_match_the_recomputing_kernel(tmp_path):
+    """round 6, njode_chain_dw.h: behind the wave-per-chain sweeps the ODE network's weight gradients are
+    outer products of operands the sweeps stored (delta1 / delta2 per pair, sums of delta1 per segment for
+    the x / tau / time columns of W1).  NJODE_CHAIN_DELTA=0 keeps k_ode_dw_pairs_mfma, which recomputes the
+    deltas from the adjoints and forms every column per pair -- the route the library also takes when the
+    delta records do not fit the record budget.  Same forward (loss, hT bit for bit), same gradient to
+    fp32 summation order; masked lockstep plan and the demo models' segment plan."""
+    n_h = 37 * 41
+    new = _run(tmp_path, 'stored', 50, {})
+    old = _run(tmp_path, 'recomputed', 50, {'NJODE_CHAIN_DELTA': '0'})
+    assert np.array_equal(new[:1 + n_h], old[:1 + n_h])
+    print('masked: rel-L2 of the gradients', rel_l2(new[1 + n_h:], old[1 + n_h:]))
+    assert rel_l2(new[1 + n_h:], old[1 + n_h:]) < 1e-6          # (measured: 9e-9)
+    assert np.abs(new[1 + n_h:] - old[1 + n_h:]).max() <= 1e-6 * np.abs(old[1 + n_h:]).max()
+    res = {}
+    for tag, env_extra in (('stored', {}), ('recomputed', {'NJODE_CHAIN_DELTA': '0'})):
+        out = str(tmp_path / (tag + '_seg.npy'))
+        p = subprocess.run([sys.executable, '-c', _SNIPPET_SEG.format(tests=TESTS, repo=REPO, out=out, B=100)],
+                           env=dict(os.environ, **env_extra), cwd=REPO, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-3000:]
+        res[tag] = np.load(out)
+    a, t = res['stored'], res['recomputed']
+    n_h = 100 * 10
+    assert np.array_equal(a[:2 + n_h], t[:2 + n_h])
+    print('demo: rel-L2 of the gradients', rel_l2(a[2 + n_h:], t[2 + n_h:]))
+    assert rel_l2(a[2 + n_h:], t[2 + n_h:]) < 1e-6              # (measured: 3e-9)
+
+
 @pytest.mark.parametrize('shape', ['demo_b100', 'masked_b37'])
 def test_a_step_reads_nothing_it_did_not_write(shape):
     """The workspace is the caller's and arrives uninitialised.  The wave-per-item route hands (step, path)
