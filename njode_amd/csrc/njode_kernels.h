@@ -163,6 +163,11 @@ struct KArgs {
   // record n_obs + b; segment plan: item r -> record r) S0 = sum delta1 | S1 = sum delta1 (t - tau) over its
   // steps, [64 lanes] each: the x / tau / time columns of dW1 (njode_chain_dw.h); grid of that kernel
   float* cseg;
+  // segment plan on the matrix cores: the saving forward packs what the backward needs of every item
+  // (Item::store_pack, [position in the item order][PACKF]) and, per tile of 16 positions, the record
+  // base of the tile's LAST Euler step (base16_s[nmax - 1]); null: the backward walks the plan's arrays
+  float* item_pack;
+  long long* tile_last;
   int dw_pair_blocks, dw_seg_blocks;
   int dw_enc_fused;   // segment plan: k_encode_rows_bwd_mfma rides in that launch (njode_chain_dw.h)
   // the barrier counters (8 words) of the plan job this call's ODE forward hosts, when the fragment-pack
@@ -400,6 +405,47 @@ template <class C> struct Item {
   }
   NJ_DEV const float* h0(const KArgs& a) const {
     return prev >= 0 ? a.h0row + (size_t)prev * C::H : a.h0start + (size_t)b * C::H;
+  }
+  // Round 6: what the ODE backward needs of the item, packed by the saving forward per position j of the
+  // item order -- [r, n, kbeg, b | tau, tanh(x)[D], pad] -- so that the backward's tile prologue is ONE
+  // load deep (order -> item arrays -> t_of_row -> time / X were four dependent loads in front of every
+  // tile: 3.5 us, profiles/r05_bwd_fixed_costs.txt).  KArgs::item_pack; null: load() as before.
+  static constexpr int PACKF = 4 + 4 * ((1 + C::D + 3) / 4);
+  NJ_DEV void store_pack(float* pack, int j) const {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    float* p = pack + (size_t)j * PACKF;
+    const v4 head = {__int_as_float(r), __int_as_float(n), __int_as_float(kbeg), __int_as_float(b)};
+    *(v4*)p = head;
+#pragma unroll
+    for (int q = 0; q < (PACKF - 4) / 4; ++q) {
+      v4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;   // 0: tau; 1 .. D: tanh(x)
+        v[e] = i == 0 ? tau : (i <= C::D ? tx[i - 1 < C::D ? (i > 0 ? i - 1 : 0) : 0] : 0.0f);
+      }
+      *(v4*)(p + 4 + 4 * q) = v;
+    }
+  }
+  NJ_DEV void load_pack(const float* pack, int j, bool valid) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const float* p = pack + (size_t)j * PACKF;
+    const v4 head = *(const v4*)p;
+    r = __float_as_int(head[0]);
+    n = valid ? __float_as_int(head[1]) : 0;
+    kbeg = __float_as_int(head[2]);
+    b = __float_as_int(head[3]);
+    prev = -1;   // (not packed: the backward does not read it)
+#pragma unroll
+    for (int q = 0; q < (PACKF - 4) / 4; ++q) {
+      const v4 v = *(const v4*)(p + 4 + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;
+        if (i == 0) tau = v[e];
+        else if (i <= C::D) tx[i - 1 < C::D ? i - 1 : 0] = v[e];
+      }
+    }
   }
 };
 

@@ -340,6 +340,13 @@ NJ_DEV void ode_fwd_split(const KArgs& a, lfp lds_raw, int worker, int n_workers
       b16_n = (SAVE || bits_ahead) ? sload_ll(a.base16_s, 0) : 0;
       if (bits_ahead) kb_r = a.dbits[(size_t)(b16_n / 16 + tile) * 64 + lane];
     }
+    if constexpr (SAVE) {
+      if (a.item_pack) {   // (for the backward's tile prologue: Item::store_pack; whichever role runs the tile there)
+        if (w == 0 && g == 0) it.store_pack(a.item_pack, j);
+        const long long bl = sload_ll(a.base16_s, nmax > 0 ? nmax - 1 : 0);
+        if (threadIdx.x == 0) a.tile_last[tile] = bl;
+      }
+    }
     vm_drain();
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;

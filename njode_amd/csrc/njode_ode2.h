@@ -489,6 +489,13 @@ NJ_DEV void ode2_fwd_single(const KArgs& a, int lane, int wave, int n_waves, int
       t_r = a.step_t[k0];
       b16_n = SAVE ? sload_ll(a.base16_s, 0) : 0;
     }
+    if constexpr (SAVE) {
+      if (a.item_pack) {   // (for the backward's tile prologue: Item::store_pack)
+        if (g == 0) it.store_pack(a.item_pack, j);
+        const long long bl = sload_ll(a.base16_s, nmax > 0 ? nmax - 1 : 0);
+        if (lane == 0) a.tile_last[tile] = bl;
+      }
+    }
     vm_drain();
     for (int s = 0; s < nmax; ++s) {
       const bool active = s < it.n;
@@ -820,7 +827,15 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
     const int j = tile * 16 + c;
     const bool valid = j < a.n_obs;
     Item<C> it;
-    it.template load<false>(a, j, valid);
+    long long b16_last = 0;
+    const bool packed = a.item_pack != nullptr;   // (uniform)
+    if (packed) {
+      // (round 6: ONE load deep -- the forward left the item and the record base of the tile's last step)
+      b16_last = sload_ll(a.tile_last, tile);
+      it.load_pack(a.item_pack, j, valid);
+    } else {
+      it.template load<false>(a, j, valid);
+    }
     float lam[M::QH];
 #pragma unroll
     for (int q = 0; q < M::QH; ++q) {
@@ -848,7 +863,7 @@ NJ_DEV void ode3_bwd_single(const KArgs& a, lfp lds_raw, int wave, int n_waves, 
 #pragma unroll
     for (int q = 0; q < M::Q1; ++q) { a1[q] = 0.0f; a2[q] = 0.0f; }
     if (nmax > 0) {   // (in the order of the steady state: the waits at the loop head count on it)
-      const float* blk = rec_block<C>(a.act, sload_ll(a.base16_s, nmax - 1), tile);
+      const float* blk = rec_block<C>(a.act, packed ? b16_last : sload_ll(a.base16_s, nmax - 1), tile);
       load_sched(nmax - 1, dt_r, t_r);
       rec_load_A<C>(blk, lane, a2, h);
       rec_load_B<C>(blk, lane, a1);
