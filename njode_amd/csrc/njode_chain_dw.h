@@ -52,7 +52,9 @@ template <class C> struct ChainDw {
   static constexpr int NS = 4 * NTX;                                                 // segment role's
   static constexpr int NRED = NP > NS ? NP : NS;
   static constexpr int EW = 16 * (W % 4) + W / 4;    // record entry of unit W: the bias unit's slot
-  static_assert(W < 64 && C::NH == 2, "a free lane for the bias unit; two hidden layers");
+  // blocks per CU the kernel is compiled for: with H <= 16 (24 accumulator tiles) a wave's tiles + two sets
+  // of operands fit 256 registers -- two waves per SIMD, the host then launches up to 512 pair blocks
+  static constexpr int BLOCKS_PER_CU = NP <= 24 ? 2 : 1;
   // unit of row 4 g + r / of column c of operand tile j (see above)
   static NJ_DEV int row_unit(int j, int g, int r) { return 16 * r + 4 * j + g; }
   static NJ_DEV int col_unit(int j, int c) { return 16 * (c & 3) + 4 * j + (c >> 2); }
@@ -88,6 +90,7 @@ NJ_DEV void ode_dw_stored_body(const KArgs& a, float* lds_raw, int block, int nb
   using T = ChainDw<C>;
   using NL = typename C::Ode;
   constexpr int H = C::H, W = C::W, D = C::D, IN0 = C::ODE_IN;
+  static_assert(W < 64 && C::NH == 2, "a free lane for the bias unit; two hidden layers");
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -320,7 +323,7 @@ NJ_DEV void ode_dw_stored_body(const KArgs& a, float* lds_raw, int block, int nb
 }
 
 template <class C>
-__global__ void __launch_bounds__(256, 1) k_ode_dw_stored(KArgs a, int nbp) {
+__global__ void __launch_bounds__(256, ChainDw<C>::BLOCKS_PER_CU) k_ode_dw_stored(KArgs a, int nbp) {
   __shared__ __attribute__((aligned(16))) float lds_raw[ChainDw<C>::NRED * 64 * 4];
   ode_dw_stored_body<C>(a, lds_raw, (int)blockIdx.x, nbp, (int)gridDim.x - nbp);
 }
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(256, 1) k_ode_dw_stored(KArgs a, int nbp) {
 // else, and at the reference's batch sizes neither pass fills the chip (B = 100: 15 + 13 us one after
 // the other)
 template <class C, bool DROP>
-__global__ void __launch_bounds__(256, 1) k_ode_dw_stored_enc(KArgs a, int nbp, int nbs) {
+__global__ void __launch_bounds__(256, ChainDw<C>::BLOCKS_PER_CU) k_ode_dw_stored_enc(KArgs a, int nbp, int nbs) {
   constexpr int LDS = ChainDw<C>::NRED * 64 * 4 > EncBwdLds<C>::FLOATS ? ChainDw<C>::NRED * 64 * 4 : EncBwdLds<C>::FLOATS;
   __shared__ __attribute__((aligned(16))) float lds_raw[LDS];
   const int block = (int)blockIdx.x;
