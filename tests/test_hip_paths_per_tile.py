@@ -152,7 +152,7 @@ np.save({out!r}, np.concatenate([[float(loss), float(loss2)], hT.detach().cpu().
 @pytest.mark.parametrize('B', [100, 200, 7, 1200])   # (1 200: more than 768 tiles of rows -- the lane masks' buffer)
 def test_wave_per_item_ode_kernels_match_the_tiles(tmp_path, B):
     """round 6, njode_chain_seg.h: the segment plan's ODE kernels with one wave per item (the default up
-    to 18 432 items + paths) against the 16-chain tiles over four waves, dropout ON -- the same keep
+    to 16 384 items + paths) against the 16-chain tiles over four waves, dropout ON -- the same keep
     masks, so loss, hT and gradient agree to fp32 summation order on the fused step and on the
     reference's call sequence (model(...); loss.backward()).  The ODE weight gradients of the new
     route come from the lockstep plan's (step, path) pair kernel on the stored adjoints."""

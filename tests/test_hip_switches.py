@@ -42,7 +42,9 @@ np.save({out!r}, np.stack(out))
 
 def _run(tmp_path, tag, env_extra):
     out = str(tmp_path / (tag + '.npy'))
-    env = dict(os.environ, **env_extra)
+    # (NJODE_SEG_CHAIN_MAX=0: the mixed matrix-core kernels these switches belong to, not the wave-per-item
+    # kernels that a batch of this size runs by default since round 6)
+    env = dict(os.environ, NJODE_SEG_CHAIN_MAX='0', **env_extra)
     p = subprocess.run([sys.executable, '-c', _SNIPPET.format(tests=TESTS, repo=REPO, out=out)], env=env,
                        cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
