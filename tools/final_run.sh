@@ -23,8 +23,8 @@ DROPOUT=0.0 BATCHES=50,800,1000,2048 python tools/bench_physionet.py 2>/dev/null
 NJODE_CHAIN_MAX=0 DROPOUT=0.1 BATCHES=50,800,1000,2048 python tools/bench_physionet.py 2>/dev/null | grep config5 | sed 's/config5-kernels/config5-kernels (NJODE_CHAIN_MAX=0: the matrix-core tiles)/' >> gpurun_out/${R}_config5_kernels.jsonl
 NJODE_CHAIN_DELTA=0 DROPOUT=0.1 BATCHES=50,800,1000,2048 python tools/bench_physionet.py 2>/dev/null | grep config5 | sed 's/config5-kernels/config5-kernels (NJODE_CHAIN_DELTA=0: the recomputing pair kernel behind the sweeps)/' >> gpurun_out/${R}_config5_kernels.jsonl
 bash tools/small_stats.sh ${R}_small100 100 > gpurun_out/${R}_small_batch_kernels.txt; bash tools/small_stats.sh ${R}_small200 200 >> gpurun_out/${R}_small_batch_kernels.txt
-python tools/bench_generic.py 2>/dev/null > gpurun_out/${R}_generic_bench.jsonl
-python tools/bench_configs.py 2>/dev/null > gpurun_out/${R}_configs_sweep.jsonl
+python tools/bench_generic.py 2>/dev/null | grep "^{" > gpurun_out/${R}_generic_bench.jsonl
+python tools/bench_configs.py 2>/dev/null | grep "^{" > gpurun_out/${R}_configs_sweep.jsonl
 python -c "
 import json
 b=json.load(open('gpurun_out/${R}_final_bench.json'))
