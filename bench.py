@@ -787,6 +787,11 @@ def main():
             out['autograd_route_ms'] = round(autograd_route_ms(dev, dt, T, step_args, args.dropout,
                                                                args.steps), 4)
             out['autograd_route_paths_per_s'] = round(B / (out['autograd_route_ms'] * 1e-3), 1)
+            # ... and at the reference's own batch size (demo.py:81): the same literal sequence, B = 100
+            b100, _ = make_batch(100, seed=4321)
+            args100 = (b100['times'], b100['time_ptr'], b100['X'].to(dev), b100['obs_idx'].to(dev, torch.int32),
+                       dt, T, b100['start_X'].to(dev), b100['n_obs_ot'].to(dev, torch.int32))
+            out['autograd_route_b100_ms'] = round(autograd_route_ms(dev, dt, T, args100, args.dropout, 50), 4)
         if world == 1 and not args.no_config5:
             c5 = config5_ms(dev, args.dropout)
             for bsz, v in c5.items():
