@@ -206,7 +206,7 @@ def test_weight_gradients_from_stored_operands_match_the_recomputing_kernel(tmp_
     assert rel_l2(a[2 + n_h:], t[2 + n_h:]) < 1e-6              # (measured: 3e-9)
 
 
-@pytest.mark.parametrize('shape', ['demo_b100', 'masked_b37'])
+@pytest.mark.parametrize('shape', ['demo_b100', 'masked_b37', 'demo_b1600'])
 def test_a_step_reads_nothing_it_did_not_write(shape):
     """The workspace is the caller's and arrives uninitialised.  The wave-per-item route hands (step, path)
     pairs to the lockstep plan's weight-gradient kernel, which reads the stored activations of EVERY pair
@@ -216,8 +216,11 @@ def test_a_step_reads_nothing_it_did_not_write(shape):
     import torch
     from hip_util import bs_batch, demo_cfg, hip_model
     from njode_amd import models, synthetic_physionet
-    if shape == 'demo_b100':
-        b, meta = bs_batch(100, seed=11, obs_perc=0.05)        # (long tails behind the last observations)
+    if shape in ('demo_b100', 'demo_b1600'):
+        # (1 600 paths: the mixed matrix-core kernels -- the item records the saving forward packs for the
+        # backward's tile prologue are the forward's to write, every step)
+        b, meta = bs_batch(100 if shape == 'demo_b100' else 1600, seed=11,
+                           obs_perc=0.05 if shape == 'demo_b100' else 0.1)   # (0.05: long tails behind the last observations)
         m = hip_model(demo_cfg(dropout=0.1)).train()
         args = (b['times'], b['time_ptr'], b['X'].cuda(), b['obs_idx'].cuda().int(), meta['dt'], meta['maturity'],
                 b['start_X'].cuda(), b['n_obs_ot'].cuda().int())
