@@ -210,12 +210,14 @@ def test_shipped_checkpoint_known_answers(tag, name):
     assert msd == pytest.approx(float(g['msd_cond_exp']), rel=1e-3)
 
 
-@pytest.mark.parametrize('n_paths', [700, 1500])
+@pytest.mark.parametrize('n_paths', [700, 1200, 1500])
 def test_larger_batch_loss_and_grads_vs_oracle(n_paths):
     """Seeded Black-Scholes batches, random-init weights: both plans and the gradient against
-    the CPU oracle.  The sizes straddle the regimes of the mixed ODE kernels (700 paths: ~440
-    tiles, backward mixed / forward all four-wide; 1 500 paths: ~940 tiles, both mixed), and
-    the fused step (loss written by the backward) is checked on the same batch."""
+    the CPU oracle.  The sizes straddle the kernel families of the segment plan (700 and 1 200 paths:
+    one wave per item, njode_chain_seg.h + the stored-operand weight gradients -- 1 200 with more than
+    768 tiles of rows; 1 500 paths: ~940 tiles on the mixed matrix-core kernels, both roles, with the
+    packed item records), and the fused step (loss written by the backward) is checked on the same
+    batch."""
     torch.manual_seed(1)
     cfg = demo_cfg()
     b, meta = bs_batch(n_paths, seed=3)
